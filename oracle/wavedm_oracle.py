@@ -1,0 +1,326 @@
+"""CPU ORACLE for the WaveDM sampling hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
+The product path (`wavedm_amd/`) never does: it fails loudly when the HIP library is missing.
+
+What it is: a from-scratch, functional, fp32 torch-CPU restatement of the reference's algorithm
+for SURVEY.md §8(a) rows a1-a17.  It works on a flat `state_dict` (name -> tensor) and plain
+tensors, has no nn.Module tree, and shares no code with the reference.  Each function cites the
+reference lines it restates.
+
+Pinning: the reference has no tests / golden vectors of its own, so this oracle is
+pinned against the reference itself, imported (with stub modules) in the build container by
+`tests/golden/make_golden.py`; that script asserts oracle == reference on every fixture it
+writes and the fixtures are committed under `tests/golden/`.  `tests/test_oracle_golden.py`
+re-checks the oracle against those fixtures on any box (no reference needed).
+
+All layouts here are the reference's: NCHW fp32.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# a1-a3  Haar wavelet-packet DWT / IDWT      (reference: models/wavelet.py:7-49)
+# ----------------------------------------------------------------------------------------------
+def haar_filters() -> torch.Tensor:
+    """(16,4,4) fp32 analysis filters f_j[p][q], j = sub-band index.
+
+    The reference loads them from `wavelet_weights_c2.pkl['rec4']` (wavelet.py:26-33): a 16x16
+    orthonormal Walsh/Haar basis with entries +-0.25.  Closed form (checked against the pickle's
+    sign matrix by tests/golden/make_golden.py):
+        f_j[p][q] = 0.25 * (-1)^( j0*(q>>1) + j1*(p>>1) + j2*(q&1) + j3*(p&1) ),  j = j3 j2 j1 j0.
+    """
+    f = torch.empty(16, 4, 4, dtype=torch.float32)
+    for j in range(16):
+        j0, j1, j2, j3 = j & 1, (j >> 1) & 1, (j >> 2) & 1, (j >> 3) & 1
+        for p in range(4):
+            for q in range(4):
+                e = j0 * (q >> 1) + j1 * (p >> 1) + j2 * (q & 1) + j3 * (p & 1)
+                f[j, p, q] = -0.25 if (e & 1) else 0.25
+    return f
+
+
+def dwt_fwd(x: torch.Tensor) -> torch.Tensor:
+    """(B,3,H,W) -> (B,48,H/4,W/4); out channel = j*3 + c  (wavelet.py:37-43).
+
+    Grouped stride-4 conv gives channel c*16+j; the reference then permutes to sub-band-major
+    j*3+c via view(B,3,16,h,w).transpose(1,2)."""
+    B, C, H, W = x.shape
+    assert C == 3 and H % 4 == 0 and W % 4 == 0
+    w = haar_filters().repeat(3, 1, 1).unsqueeze(1)            # (48,1,4,4): row c*16+j = f_j
+    y = F.conv2d(x, w, stride=4, groups=3)                     # (B, c*16+j, h, w)
+    h, wd = H // 4, W // 4
+    return y.view(B, 3, 16, h, wd).transpose(1, 2).reshape(B, 48, h, wd)
+
+
+def dwt_inv(y: torch.Tensor) -> torch.Tensor:
+    """(B,48,h,w) with channel j*3+c -> (B,3,4h,4w)  (wavelet.py:44-49)."""
+    B, C, h, wd = y.shape
+    assert C == 48
+    w = haar_filters().repeat(3, 1, 1).unsqueeze(1)
+    yy = y.view(B, 16, 3, h, wd).transpose(1, 2).reshape(B, 48, h, wd)   # back to c*16+j
+    return F.conv_transpose2d(yy, w, stride=4, groups=3)
+
+
+def data_transform(x):             # restoration.py:8-9
+    return 2 * x - 1.0
+
+
+def inverse_data_transform(x):     # restoration.py:12-13
+    return torch.clamp((x + 1.0) / 2.0, 0.0, 1.0)
+
+
+# ----------------------------------------------------------------------------------------------
+# a4-a12  UNet                                (reference: models/unet.py:10-395)
+# ----------------------------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """unet.py:10-28: [sin(t*w_i), cos(t*w_i)], w_i = exp(-i*ln(1e4)/(dim/2-1))."""
+    assert t.dim() == 1
+    half = dim // 2
+    w = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    e = t.float()[:, None] * w[None, :]
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+    if dim % 2 == 1:
+        e = F.pad(e, (0, 1, 0, 0))
+    return e
+
+
+def silu(x):                       # unet.py:31-33
+    return x * torch.sigmoid(x)
+
+
+def group_norm(sd, name, x):       # unet.py:36-37: 32 groups, eps 1e-6, affine
+    return F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], eps=1e-6)
+
+
+def conv(sd, name, x, stride=1, padding=0):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding)
+
+
+def linear(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def resnet_block(sd, name, x, temb):
+    """unet.py:119-138."""
+    h = conv(sd, name + ".conv1", silu(group_norm(sd, name + ".norm1", x)), padding=1)
+    h = h + linear(sd, name + ".temb_proj", silu(temb))[:, :, None, None]
+    h = conv(sd, name + ".conv2", silu(group_norm(sd, name + ".norm2", h)), padding=1)   # dropout p=0
+    if (name + ".nin_shortcut.weight") in sd:
+        x = conv(sd, name + ".nin_shortcut", x)
+    return x + h
+
+
+def attn_block(sd, name, x):
+    """unet.py:168-193: single head, scale C^-0.5, softmax over keys."""
+    h = group_norm(sd, name + ".norm", x)
+    q, k, v = conv(sd, name + ".q", h), conv(sd, name + ".k", h), conv(sd, name + ".v", h)
+    b, c, hh, ww = q.shape
+    n = hh * ww
+    q = q.reshape(b, c, n).permute(0, 2, 1)          # b, n, c
+    k = k.reshape(b, c, n)                           # b, c, n
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))        # b, n(query), n(key)
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, n)
+    o = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + conv(sd, name + ".proj_out", o)
+
+
+def downsample(sd, name, x):
+    """unet.py:71-78: zero-pad right/bottom by one, conv3x3 stride 2 pad 0."""
+    return conv(sd, name + ".conv", F.pad(x, (0, 1, 0, 1)), stride=2)
+
+
+def upsample(sd, name, x):
+    """unet.py:51-56: nearest x2, conv3x3 pad 1."""
+    return conv(sd, name + ".conv", F.interpolate(x, scale_factor=2.0, mode="nearest"), padding=1)
+
+
+def unet_forward(sd, config, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """unet.py:346-395 with use_window / wavelet_in_unet off (raindrop_wavelet.yml).
+
+    x: (B, 96, R, R) = [x_cond 0:48 | x_t 48:51 | x_other 51:96], t: (n,) float, n in {1, B}.
+    """
+    m = config.model
+    ch, ch_mult = m.ch, tuple(m.ch_mult)
+    nres, nrb, attn_res = len(ch_mult), m.num_res_blocks, list(m.attn_resolutions)
+    assert x.shape[2] == x.shape[3] == config.data.image_size
+
+    temb = timestep_embedding(t, ch)
+    temb = linear(sd, "temb.dense.1", silu(linear(sd, "temb.dense.0", temb)))
+
+    res = config.data.image_size
+    hs = [conv(sd, "conv_in", x, padding=1)]
+    for l in range(nres):
+        for b in range(nrb):
+            h = resnet_block(sd, f"down.{l}.block.{b}", hs[-1], temb)
+            if res in attn_res:
+                h = attn_block(sd, f"down.{l}.attn.{b}", h)
+            hs.append(h)
+        if l != nres - 1:
+            hs.append(downsample(sd, f"down.{l}.downsample", hs[-1]))
+            res //= 2
+
+    h = hs[-1]
+    h = resnet_block(sd, "mid.block_1", h, temb)
+    h = attn_block(sd, "mid.attn_1", h)
+    h = resnet_block(sd, "mid.block_2", h, temb)
+
+    for l in reversed(range(nres)):
+        for b in range(nrb + 1):
+            h = resnet_block(sd, f"up.{l}.block.{b}", torch.cat([h, hs.pop()], dim=1), temb)
+            if res in attn_res:
+                h = attn_block(sd, f"up.{l}.attn.{b}", h)
+        if l != 0:
+            h = upsample(sd, f"up.{l}.upsample", h)
+            res *= 2
+
+    return conv(sd, "conv_out", silu(group_norm(sd, "norm_out", h)), padding=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a13-a16  schedule, grid, DDIM sampler       (reference: models/ddm_wavelet.py, utils/sampling.py)
+# ----------------------------------------------------------------------------------------------
+def beta_schedule(config) -> torch.Tensor:
+    """ddm_wavelet.py:87-105 (linear only is used) -> fp32 as at :177."""
+    d = config.diffusion
+    assert d.beta_schedule == "linear"
+    b = np.linspace(d.beta_start, d.beta_end, d.num_diffusion_timesteps, dtype=np.float64)
+    return torch.from_numpy(b).float()
+
+
+def compute_alpha(betas: torch.Tensor, t: int) -> torch.Tensor:
+    """utils/sampling.py:10-13: abar(t) = cumprod(1 - [0, beta])[t+1] in fp32; abar(-1) = 1."""
+    b = torch.cat([torch.zeros(1), betas], dim=0)
+    return (1 - b).cumprod(dim=0)[t + 1]
+
+
+def timestep_seq(num_timesteps: int, sampling_timesteps: int):
+    """ddm_wavelet.py:296-297."""
+    skip = num_timesteps // sampling_timesteps
+    return list(range(0, num_timesteps, skip))
+
+
+def overlapping_grid_indices(h: int, w: int, p: int, r: int = 16):
+    """ddm_wavelet.py:426-435 (dup restoration.py:187-196)."""
+    r = 16 if r is None else r
+    h_list = list(range(0, h - p + 1, r))
+    w_list = list(range(0, w - p + 1, r))
+    if h_list[-1] + p < h:
+        h_list.append(h - p)
+    if w_list[-1] + p < w:
+        w_list.append(w - p)
+    return h_list, w_list
+
+
+def grid_corners(h, w, p, r=16):
+    hl, wl = overlapping_grid_indices(h, w, p, r)
+    return [(i, j) for i in hl for j in wl]          # ddm_wavelet.py:419
+
+
+def overlap_count_mask(h, w, p, corners) -> torch.Tensor:
+    """ddm_wavelet.py:451-453 (integer-valued)."""
+    m = torch.zeros(h, w, dtype=torch.int32)
+    for (hi, wi) in corners:
+        m[hi:hi + p, wi:wi + p] += 1
+    return m
+
+
+def ddim_overlapping(sd, config, x, x_cond, x_other, corners, p, sampling_timesteps,
+                     betas=None, model=None, chunk=8):
+    """ddm_wavelet.py:437-506 with eta=0, begin_from_noise=True, use_other=True.
+
+    x: (1,3,H,W) start noise, x_cond: (1,48,H,W), x_other: (1,45,H,W).
+    Returns (xs, x0_preds) lists like the reference (len S+1 and S).
+    `model(x96, t)` defaults to this file's `unet_forward`.
+    The reference draws `randn_like` every step and multiplies it by c1 = 0: no effect on values.
+    """
+    if betas is None:
+        betas = beta_schedule(config)
+    if model is None:
+        model = lambda x96, t: unet_forward(sd, config, x96, t)
+    n = x.size(0)
+    seq = timestep_seq(config.diffusion.num_diffusion_timesteps, sampling_timesteps)
+    seq_next = [-1] + list(seq[:-1])
+    xs, x0_preds = [x], []
+    mask = torch.zeros_like(x)
+    for (hi, wi) in corners:
+        mask[:, :, hi:hi + p, wi:wi + p] += 1
+    with torch.no_grad():
+        for i_t, j_t in zip(reversed(seq), reversed(seq_next)):
+            t = torch.ones(n) * i_t
+            at, at_next = compute_alpha(betas, i_t), compute_alpha(betas, j_t)
+            xt = xs[-1]
+            acc = torch.zeros_like(x)
+            xt_p = torch.cat([xt[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
+            xc_p = torch.cat([x_cond[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
+            xo_p = torch.cat([x_other[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
+            for i in range(0, len(corners), chunk):
+                x96 = torch.cat([xc_p[i:i + chunk], xt_p[i:i + chunk], xo_p[i:i + chunk]], dim=1)
+                out = model(x96, t)
+                for idx, (hi, wi) in enumerate(corners[i:i + chunk]):
+                    acc[0, :, hi:hi + p, wi:wi + p] += out[idx]
+            et = acc / mask
+            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+            x0_preds.append(x0_t)
+            c2 = (1 - at_next).sqrt()                      # c1 = 0 for eta = 0
+            xs.append(at_next.sqrt() * x0_t + c2 * et)
+    return xs, x0_preds
+
+
+def ddim_batch(sd, config, x_T, x_cond, x_other, sampling_timesteps, betas=None, chunk=8):
+    """B independent 64x64 patches, each the single-corner case of `ddim_overlapping`
+    (corners=[(0,0)], p=H): what BASELINE.json's configs 0-3 run.  Per-image trajectories are
+    independent, so this is the reference path applied image by image, batched through the UNet
+    in chunks.  Returns (xs, x0_preds) as lists of (B,3,R,R)."""
+    if betas is None:
+        betas = beta_schedule(config)
+    B = x_T.size(0)
+    seq = timestep_seq(config.diffusion.num_diffusion_timesteps, sampling_timesteps)
+    seq_next = [-1] + list(seq[:-1])
+    xs, x0_preds = [x_T], []
+    with torch.no_grad():
+        for i_t, j_t in zip(reversed(seq), reversed(seq_next)):
+            t = torch.ones(1) * i_t
+            at, at_next = compute_alpha(betas, i_t), compute_alpha(betas, j_t)
+            xt = xs[-1]
+            et = torch.cat([unet_forward(sd, config,
+                                         torch.cat([x_cond[i:i + chunk], xt[i:i + chunk],
+                                                    x_other[i:i + chunk]], dim=1), t)
+                            for i in range(0, B, chunk)], dim=0)
+            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+            x0_preds.append(x0_t)
+            xs.append(at_next.sqrt() * x0_t + (1 - at_next).sqrt() * et)
+    return xs, x0_preds
+
+
+# ----------------------------------------------------------------------------------------------
+# a17  restoration glue                       (reference: models/restoration.py:63-168)
+# ----------------------------------------------------------------------------------------------
+def restore(sd, config, x01, x_T, sampling_timesteps, r=16, hfrm=None, keep=-5):
+    """restoration.py:70-134 for one image: x01 (1,3,H,W) in [0,1] -> restored (1,3,H,W) in [0,1].
+
+    `hfrm` is the out-of-path high-frequency module (restoration.py:94); identity stand-in when
+    None.  `x_T` replaces the reference's `torch.randn` (restoration.py:177) so
+    the result is reproducible.  Output = IDWT(cat[x0_preds[keep][:, :3], hfrm_wav[:, 3:]])."""
+    p = config.data.image_size
+    x_cond = dwt_fwd(data_transform(x01))
+    hf = x01 if hfrm is None else hfrm(x01)
+    hf_wav = dwt_fwd(data_transform(hf))
+    x_other = hf_wav[:, config.model.other_channels_begin:]
+    corners = grid_corners(x_cond.shape[2], x_cond.shape[3], p, r)
+    xs, x0_preds = ddim_overlapping(sd, config, x_T, x_cond, x_other, corners, p, sampling_timesteps)
+    pc = config.model.pred_channels
+    out = torch.cat([x0_preds[keep][:, :pc], hf_wav[:, pc:]], dim=1)
+    return inverse_data_transform(dwt_inv(out)), xs, x0_preds
+
+
+def torch_psnr(tar, prd):          # utils/metrics.py:7-11
+    d = torch.clamp(prd, 0, 1) - torch.clamp(tar, 0, 1)
+    return 20 * torch.log10(1 / (d ** 2).mean().sqrt())

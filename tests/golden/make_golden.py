@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE ITSELF (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/*.npz
+
+The reference (pure Python, /root/reference) has no tests or golden vectors of its own
+(SURVEY.md §4), so parity is pinned by importing it here with three shims:
+stub `torchvision` / `cv2` / `skimage` modules, cwd = /root/reference (relative pickle path,
+wavelet.py:7), and an un-constructed `DenoisingDiffusion_Wavelet` instance (its ctor needs an
+absent HFRM checkpoint + NCCL + CUDA DDP) whose attributes are set by hand so the *bound
+reference methods* `sample_image` / `generalized_steps_overlapping` /
+`overlapping_grid_indices` and `DiffusiveRestoration.restore` run unmodified on CPU.
+
+Every fixture holds DATA only (inputs are regenerated from seeds; outputs are stored, large ones
+sub-sampled with a fixed stride).  While writing them the script also asserts that
+`oracle/wavedm_oracle.py` reproduces the reference on each case (<= 1e-5 max-norm relative for
+floats, exact for integers); that is what "pins" the oracle.
+"""
+import argparse
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from wavedm_amd import procedural as P           # noqa: E402
+from oracle import wavedm_oracle as O            # noqa: E402
+
+SAVED_IMAGES = {}
+
+
+def install_stubs():
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+
+    def save_image(img, path, normalize=False, **kw):
+        SAVED_IMAGES[os.path.basename(path)] = img.detach().clone()
+    tvu.save_image = save_image
+    tvu.make_grid = lambda x, **kw: x
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvf.crop = lambda img, t, l, h, w: img[..., t:t + h, l:l + w]
+    tvt.functional = tvf
+    tv.utils, tv.transforms = tvu, tvt
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules.update({"torchvision": tv, "torchvision.utils": tvu, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf, "torchvision.models": tvm})
+    cv2 = types.ModuleType("cv2")
+    sk = types.ModuleType("skimage")
+    skc = types.ModuleType("skimage.color")
+    sk.color = skc
+    sys.modules.update({"cv2": cv2, "skimage": sk, "skimage.color": skc})
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def check(name, got, want, tol=1e-5):
+    e = rel_err(got, want)
+    print(f"  oracle vs reference  {name:<28s} rel_linf = {e:.3e}")
+    assert e <= tol, (name, e)
+
+
+def sub(t, stride):
+    """Fixed-stride subsample of a flattened tensor (keeps fixtures small)."""
+    return t.detach().flatten()[::stride].contiguous().numpy()
+
+
+def seeded(shape, seed, kind="randn"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn if kind == "randn" else torch.rand)(*shape, generator=g, dtype=torch.float32)
+
+
+def block_sd(prefix, shapes, seed=61):
+    return {k: torch.from_numpy(P.procedural_tensor(k, s, seed)) for k, s in shapes.items()
+            if k.startswith(prefix)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true", help="skip the full-width (156 M) cases")
+    args = ap.parse_args()
+
+    install_stubs()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    import models                                              # noqa: F401  (reference package)
+    from models import unet as RU
+    from models.wavelet import WaveletTransform
+    from models.ddm_wavelet import DenoisingDiffusion_Wavelet, get_beta_schedule
+    from models.restoration import DiffusiveRestoration
+    from utils.sampling import compute_alpha
+    torch.set_grad_enabled(False)
+
+    out = lambda n: os.path.join(HERE, n)
+
+    # ------------------------------------------------------------------ integer tables
+    print("[tables]")
+    dec = WaveletTransform(scale=2, dec=True)
+    rec = WaveletTransform(scale=2, dec=False)
+    w = dec.conv.weight.detach()                                # (48,1,4,4)
+    assert torch.equal(w[:16], w[16:32]) and torch.equal(w[:16], w[32:])
+    assert float(w.abs().min()) == 0.25 == float(w.abs().max())
+    rec4_sign = torch.sign(w[:16, 0]).reshape(16, 16).to(torch.int8)
+    assert torch.equal(torch.sign(O.haar_filters()).reshape(16, 16).to(torch.int8), rec4_sign)
+    assert torch.equal(O.haar_filters(), w[:16, 0])
+    # sub-band permutation: feed one-hot conv channels through the reference's view/transpose
+    perm = np.zeros(48, dtype=np.int32)                          # out channel -> conv channel c*16+j
+    probe = torch.arange(48, dtype=torch.float32).view(1, 48, 1, 1)
+    osz = probe.size()
+    perm[:] = probe.view(1, 3, -1, 1, 1).transpose(1, 2).contiguous().view(osz).flatten().numpy()
+    assert all(perm[j * 3 + c] == c * 16 + j for j in range(16) for c in range(3))
+    ns = object.__new__(DenoisingDiffusion_Wavelet)
+    tables = {"rec4_sign": rec4_sign.numpy(), "subband_perm": perm}
+    for (h, wd, p, r) in [(64, 64, 64, 16), (120, 180, 64, 16), (128, 128, 64, 16), (65, 70, 64, 16),
+                          (30, 45, 16, 4), (16, 16, 16, 4)]:
+        hl, wl = ns.overlapping_grid_indices(torch.zeros(1, 1, h, wd), output_size=p, r=r)
+        ohl, owl = O.overlapping_grid_indices(h, wd, p, r)
+        assert hl == ohl and wl == owl
+        tables[f"grid_h_{h}_{wd}_{p}_{r}"] = np.array(hl, dtype=np.int32)
+        tables[f"grid_w_{h}_{wd}_{p}_{r}"] = np.array(wl, dtype=np.int32)
+    corners = O.grid_corners(120, 180, 64, 16)
+    mask = torch.zeros(1, 1, 120, 180)
+    for (hi, wi) in corners:                                     # ddm_wavelet.py:451-453
+        mask[:, :, hi:hi + 64, wi:wi + 64] += 1
+    assert torch.equal(mask[0, 0].to(torch.int32), O.overlap_count_mask(120, 180, 64, corners))
+    tables["mask_120_180_64_16"] = mask[0, 0].to(torch.int16).numpy()
+    for S in (10, 25, 50, 100):
+        seq = list(range(0, 1000, 1000 // S))                    # ddm_wavelet.py:296-297
+        assert seq == O.timestep_seq(1000, S)
+        tables[f"seq_{S}"] = np.array(seq, dtype=np.int32)
+    cfg_full = P.raindrop_wavelet_config()
+    betas = torch.from_numpy(get_beta_schedule(beta_schedule="linear", beta_start=1e-4, beta_end=0.02,
+                                               num_diffusion_timesteps=1000)).float()
+    assert torch.equal(betas, O.beta_schedule(cfg_full))
+    abar = torch.stack([compute_alpha(betas, torch.tensor([t])).flatten()[0] for t in range(-1, 1000)])
+    oabar = torch.stack([O.compute_alpha(betas, t) for t in range(-1, 1000)])
+    assert torch.equal(abar, oabar)
+    tables["alpha_bar_m1_to_999"] = abar.numpy()
+    np.savez_compressed(out("tables.npz"), **tables)
+
+    # ------------------------------------------------------------------ DWT known answers
+    print("[dwt]")
+    x = seeded((2, 3, 16, 16), 1, "rand") * 2 - 1
+    y = dec(x)
+    xr = rec(y)
+    check("dwt_fwd", O.dwt_fwd(x), y, 1e-6)
+    check("dwt_inv", O.dwt_inv(y), xr, 1e-6)
+    x2 = seeded((1, 3, 8, 12), 2, "randn")
+    y2 = dec(x2)
+    check("dwt_fwd ragged", O.dwt_fwd(x2), y2, 1e-6)
+    np.savez_compressed(out("dwt.npz"), x=x.numpy(), y=y.numpy(), xr=xr.numpy(), x2=x2.numpy(), y2=y2.numpy())
+
+    # ------------------------------------------------------------------ per-block outputs
+    print("[blocks]")
+    blocks = {}
+
+    def load(mod, prefix, seed=61):
+        sd = {}
+        for k, v in mod.state_dict().items():
+            sd[k] = torch.from_numpy(P.procedural_tensor(prefix + "." + k, tuple(v.shape), seed))
+        mod.load_state_dict(sd, strict=True)
+        return {prefix + "." + k: v for k, v in sd.items()}
+
+    # ResnetBlock with shortcut 64->128 @16, B=2, n_t = B
+    rb = RU.ResnetBlock(in_channels=64, out_channels=128, dropout=0.0, temb_channels=512).eval()
+    sd = load(rb, "rb_a")
+    xin, temb = seeded((2, 64, 16, 16), 10), seeded((2, 512), 11)
+    yref = rb(xin, temb)
+    check("resblock 64->128@16", O.resnet_block(sd, "rb_a", xin, temb), yref)
+    blocks["rb_a"] = yref.numpy()
+    # ResnetBlock no shortcut 128->128 @8, temb broadcast n_t = 1
+    rb = RU.ResnetBlock(in_channels=128, out_channels=128, dropout=0.0, temb_channels=512).eval()
+    sd = load(rb, "rb_b")
+    xin, temb = seeded((2, 128, 8, 8), 12), seeded((1, 512), 13)
+    yref = rb(xin, temb)
+    check("resblock 128->128@8", O.resnet_block(sd, "rb_b", xin, temb), yref)
+    blocks["rb_b"] = yref.numpy()
+    # ResnetBlock on a concat input 384->128 @16 (group width 12, straddle-free) B=1
+    rb = RU.ResnetBlock(in_channels=384, out_channels=128, dropout=0.0, temb_channels=512).eval()
+    sd = load(rb, "rb_c")
+    xin, temb = seeded((1, 384, 16, 16), 14), seeded((1, 512), 15)
+    yref = rb(xin, temb)
+    check("resblock 384->128@16", O.resnet_block(sd, "rb_c", xin, temb), yref)
+    blocks["rb_c"] = yref.numpy()
+    # ResnetBlock 1280->768 @8: GroupNorm group (40 ch) straddles the [h(768) | skip(512)] seam
+    rb = RU.ResnetBlock(in_channels=1280, out_channels=768, dropout=0.0, temb_channels=512).eval()
+    sd = load(rb, "rb_d")
+    xin, temb = seeded((1, 1280, 8, 8), 16), seeded((1, 512), 17)
+    yref = rb(xin, temb)
+    check("resblock 1280->768@8", O.resnet_block(sd, "rb_d", xin, temb), yref)
+    blocks["rb_d"] = yref.numpy()
+    # AttnBlock at the real shape: C=512, 16x16 (N=256), B=1 (subsampled) and C=64 @8x8, B=2
+    ab = RU.AttnBlock(512).eval()
+    sd = load(ab, "at_a")
+    xin = seeded((1, 512, 16, 16), 20)
+    yref = ab(xin)
+    check("attn 512@16", O.attn_block(sd, "at_a", xin), yref)
+    blocks["at_a_s5"] = sub(yref, 5)
+    ab = RU.AttnBlock(64).eval()
+    sd = load(ab, "at_b")
+    xin = seeded((2, 64, 8, 8), 21)
+    yref = ab(xin)
+    check("attn 64@8", O.attn_block(sd, "at_b", xin), yref)
+    blocks["at_b"] = yref.numpy()
+    # mid attention shape: C=768 @8x8 (N=64), B=1
+    ab = RU.AttnBlock(768).eval()
+    sd = load(ab, "at_c")
+    xin = seeded((1, 768, 8, 8), 22)
+    yref = ab(xin)
+    check("attn 768@8", O.attn_block(sd, "at_c", xin), yref)
+    blocks["at_c"] = yref.numpy()
+    # Downsample / Upsample
+    ds = RU.Downsample(64, True).eval()
+    sd = load(ds, "ds_a")
+    xin = seeded((2, 64, 16, 16), 30)
+    yref = ds(xin)
+    check("downsample 64@16", O.downsample(sd, "ds_a", xin), yref)
+    blocks["ds_a"] = yref.numpy()
+    us = RU.Upsample(64, True).eval()
+    sd = load(us, "us_a")
+    xin = seeded((2, 64, 8, 8), 31)
+    yref = us(xin)
+    check("upsample 64@8", O.upsample(sd, "us_a", xin), yref)
+    blocks["us_a"] = yref.numpy()
+    # timestep embedding
+    for tt in (0, 10, 990):
+        e = RU.get_timestep_embedding(torch.tensor([float(tt)]), 128)
+        check(f"timestep_embedding t={tt}", O.timestep_embedding(torch.tensor([float(tt)]), 128), e, 1e-6)
+        blocks[f"temb_{tt}"] = e.numpy()
+    np.savez_compressed(out("blocks.npz"), **blocks)
+
+    # ------------------------------------------------------------------ reduced UNet + sampler
+    print("[reduced]")
+    cfg = P.reduced_config()
+    cfg.device = torch.device("cpu")
+    sd_r = P.procedural_state_dict(cfg, seed=61)
+    net = RU.DiffusionUNet(cfg).eval()
+    assert list(net.state_dict().keys()) == list(sd_r.keys()), "procedural key order != reference"
+    net.load_state_dict(sd_r, strict=True)
+    red = {}
+    x96 = seeded((2, 96, 16, 16), 40)
+    for name, t in (("t500", torch.tensor([500.0])), ("t_per_image", torch.tensor([990.0, 10.0]))):
+        yref = net(x96, t)
+        check(f"reduced unet fwd {name}", O.unet_forward(sd_r, cfg, x96, t), yref)
+        red["fwd_" + name] = yref.numpy()
+
+    def ref_diffusion(cfg_, net_, S):
+        d = object.__new__(DenoisingDiffusion_Wavelet)
+        d.config, d.device, d.model = cfg_, torch.device("cpu"), net_
+        d.args = SimpleNamespace(sampling_timesteps=S, resume="", local_rank=0, image_folder="/tmp/x",
+                                 test_set="raindrop", grid_r=16)
+        d.betas = torch.from_numpy(get_beta_schedule(
+            beta_schedule="linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+        d.num_timesteps = 1000
+        d.wavelet_dec, d.wavelet_rec = dec, rec
+        d.generator = lambda x_: x_                               # identity HFRM stand-in
+        return d
+
+    # 10-step sampler on 2 independent 16x16 patches through the bound reference methods
+    rainy, x_T = P.synthetic_batch(2, patch_px=64, seed=61)
+    x_cond = dec(2 * rainy - 1)
+    x_other = x_cond[:, 3:]
+    d = ref_diffusion(cfg, net, 10)
+    xs_l, x0_l = [], []
+    for i in range(2):
+        xs, x0p = d.sample_image(x_cond[i:i + 1], x_T[i:i + 1], x_other=x_other[i:i + 1], last=False,
+                                 patch_locs=[(0, 0)], patch_size=16, use_other=True)
+        xs_l.append(xs[-1]); x0_l.append(x0p[-5])
+    ref_xs, ref_x0 = torch.cat(xs_l), torch.cat(x0_l)
+    oxs, ox0 = O.ddim_batch(sd_r, cfg, x_T, O.dwt_fwd(2 * rainy - 1), O.dwt_fwd(2 * rainy - 1)[:, 3:], 10)
+    check("reduced sampler xs[-1]", oxs[-1], ref_xs)
+    check("reduced sampler x0[-5]", ox0[-5], ref_x0)
+    red["samp_xs_last"], red["samp_x0_m5"] = ref_xs.numpy(), ref_x0.numpy()
+    np.savez_compressed(out("reduced.npz"), **red)
+
+    # ------------------------------------------------------------------ C4-shaped stitch (reduced model)
+    print("[stitch]")
+    st = {}
+    g = torch.Generator().manual_seed(77)
+    img = torch.rand(1, 3, 120, 180, generator=g)                 # -> 30 x 45 wavelet domain, p=16, r=4
+    gt = torch.rand(1, 3, 120, 180, generator=g)
+    S = 6
+    d = ref_diffusion(cfg, net, S)
+    rargs = SimpleNamespace(resume="", image_folder="/tmp/wdm_golden", sampling_timesteps=S)
+    import utils as RUT
+    RUT.calculate_psnr = lambda *a, **k: 0.0                      # numpy/cv2 metric: not on the path
+    RUT.calculate_psnr_in_GPU = lambda *a, **k: torch.tensor(0.0)
+    restorer = DiffusiveRestoration(d, rargs, cfg)
+    torch.manual_seed(123)
+    SAVED_IMAGES.clear()
+    restorer.restore([(torch.cat([img, gt], dim=1), "img0", torch.zeros(1))], validation="raindrop", r=4)
+    ref_out = SAVED_IMAGES["img0_output.png"]
+    torch.manual_seed(123)
+    x_T_full = torch.randn(1, 3, 30, 45)                          # the draw restoration.py:177 made
+    o_out, o_xs, o_x0 = O.restore(sd_r, cfg, img, x_T_full, S, r=4)
+    check("restore() stitched output", o_out, ref_out)
+    st["out"] = ref_out.numpy()
+    st["x_T"] = x_T_full.numpy()
+    st["n_corners"] = np.array(len(O.grid_corners(30, 45, 16, 4)), dtype=np.int32)
+    np.savez_compressed(out("stitch.npz"), **st)
+
+    # ------------------------------------------------------------------ full-width (156 M params)
+    if not args.skip_full:
+        print("[full]  (generating 156 M procedural weights)")
+        cfg = P.raindrop_wavelet_config()
+        cfg.device = torch.device("cpu")
+        sd_f = P.procedural_state_dict(cfg, seed=61)
+        net = RU.DiffusionUNet(cfg).eval()
+        assert list(net.state_dict().keys()) == list(sd_f.keys())
+        net.load_state_dict(sd_f, strict=True)
+        nparams = sum(v.numel() for v in sd_f.values())
+        print("  params:", nparams)
+        full = {"n_params": np.array(nparams, dtype=np.int64)}
+        rainy, x_T = P.synthetic_batch(4, patch_px=256, seed=61)
+        x_cond = dec(2 * rainy - 1)
+        x_other = x_cond[:, 3:]
+        x96 = torch.cat([x_cond[:2], x_T[:2], x_other[:2]], dim=1)
+        yref = net(x96, torch.tensor([990.0]))
+        check("full unet fwd t=990", O.unet_forward(sd_f, cfg, x96, torch.tensor([990.0])), yref)
+        full["fwd_t990"] = yref.numpy()
+        d = ref_diffusion(cfg, net, 10)
+        xs_l, x0_l = [], []
+        for i in range(4):                                        # config 0: 4x64x64, 10 DDIM steps
+            xs, x0p = d.sample_image(x_cond[i:i + 1], x_T[i:i + 1], x_other=x_other[i:i + 1], last=False,
+                                     patch_locs=[(0, 0)], patch_size=64, use_other=True)
+            xs_l.append(xs[-1]); x0_l.append(x0p[-5])
+        ref_xs, ref_x0 = torch.cat(xs_l), torch.cat(x0_l)
+        oxs, ox0 = O.ddim_batch(sd_f, cfg, x_T, O.dwt_fwd(2 * rainy - 1), O.dwt_fwd(2 * rainy - 1)[:, 3:], 10,
+                                chunk=1)
+        check("C0 sampler xs[-1]", oxs[-1], ref_xs)
+        check("C0 sampler x0[-5]", ox0[-5], ref_x0)
+        full["c0_xs_last"], full["c0_x0_m5"] = ref_xs.numpy(), ref_x0.numpy()
+        np.savez_compressed(out("full.npz"), **full)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

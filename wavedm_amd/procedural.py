@@ -1,0 +1,196 @@
+"""Procedural (seeded, reproducible) weights and synthetic inputs.
+
+No pretrained checkpoint ships with the reference (the HFRM file
+`saved_models/raindrop/lastest.pth` and the DDPM ckpt are both absent) and 156 M random weights
+cannot be committed, so tests, golden fixtures and bench.py all re-create the *same* weights from a
+named, seeded generator on whatever box they run on (SURVEY.md §8c / Appendix B recipe):
+
+    for each state_dict entry `name`:  rng = numpy PCG64(seed ^ crc32(name))
+        ndim > 1           -> N(0,1) / sqrt(fan_in)        (conv OIHW, Linear [out,in])
+        1-D "*.weight"     -> 1 + 0.1 N(0,1)               (GroupNorm gamma)
+        everything else    -> 0.1 N(0,1)                   (biases, GroupNorm beta)
+
+The state_dict key list / shapes follow the reference model's parameter naming
+(`models/unet.py:196-307`): they are generated here from the config alone.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------------------------
+# config helpers
+# ----------------------------------------------------------------------------------------------
+def dict2namespace(d):
+    """YAML dict -> nested namespace (same contract as the reference's `eval_diffusion.py:47-55`)."""
+    ns = SimpleNamespace()
+    for k, v in d.items():
+        setattr(ns, k, dict2namespace(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def raindrop_wavelet_config(image_size: int = 64, ch: int = 128, ch_mult=(1, 2, 4, 6),
+                            num_res_blocks: int = 2, attn_resolutions=(16,)):
+    """The keys of `configs/raindrop_wavelet.yml` that the sampling path reads."""
+    return dict2namespace({
+        "data": {"dataset": "RainDrop", "image_size": image_size, "patch_size": image_size * 4,
+                 "lap": False, "global_attn": False, "wavelet": True, "wavelet_in_unet": False,
+                 "use_window": False, "window_size": 2, "begin_from_noise": True,
+                 "num_workers": 0, "data_dir": "", "conditional": True},
+        "model": {"pred_channels": 3, "use_other_channels": True, "other_channels_begin": 3,
+                  "use_gt_in_train": True, "in_channels": 48, "out_ch": 3, "ch": ch,
+                  "ch_mult": list(ch_mult), "num_res_blocks": num_res_blocks,
+                  "attn_resolutions": list(attn_resolutions), "dropout": 0.0, "ema_rate": 0.999,
+                  "ema": True, "resamp_with_conv": True},
+        "diffusion": {"beta_schedule": "linear", "beta_start": 0.0001, "beta_end": 0.02,
+                      "num_diffusion_timesteps": 1000},
+        "sampling": {"batch_size": 1, "last_only": True},
+    })
+
+
+def reduced_config():
+    """Reduced-width fixture model of SURVEY.md §8c (1.03 M params, attention at res 8)."""
+    return raindrop_wavelet_config(image_size=16, ch=32, ch_mult=(1, 2), attn_resolutions=(8,))
+
+
+def unet_in_channels(config) -> int:
+    m = config.model
+    if m.use_other_channels:
+        return m.in_channels * 2 + m.pred_channels - m.other_channels_begin
+    return m.in_channels + m.pred_channels
+
+
+# ----------------------------------------------------------------------------------------------
+# state_dict layout (names + shapes) from the config alone
+# ----------------------------------------------------------------------------------------------
+def unet_param_shapes(config) -> "OrderedDict[str, tuple]":
+    """Ordered {state_dict key: shape} of the wavelet-domain DiffusionUNet for `config`.
+
+    Mirrors the module tree of the reference (`models/unet.py:197-307`): temb.dense.{0,1},
+    conv_in, down.{l}.block.{b}.*, down.{l}.attn.{b}.*, down.{l}.downsample.conv, mid.*,
+    up.{l}.block.{b}.*, up.{l}.attn.{b}.*, up.{l}.upsample.conv, norm_out, conv_out.
+    Registration order matters only for reproducing `state_dict()` key order; values are keyed
+    by name.
+    """
+    m = config.model
+    ch, out_ch, ch_mult = m.ch, m.out_ch, tuple(m.ch_mult)
+    nrb, attn_res = m.num_res_blocks, list(m.attn_resolutions)
+    in_ch = unet_in_channels(config)
+    temb_ch = ch * 4
+    shapes: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        shapes[name + ".weight"] = (cout, cin, k, k)
+        shapes[name + ".bias"] = (cout,)
+
+    def lin(name, cin, cout):
+        shapes[name + ".weight"] = (cout, cin)
+        shapes[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shapes[name + ".weight"] = (c,)
+        shapes[name + ".bias"] = (c,)
+
+    def resblock(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cin, cout, 3)
+        lin(name + ".temb_proj", temb_ch, cout)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cin, cout, 1)
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for p in ("q", "k", "v", "proj_out"):
+            conv(name + "." + p, c, c, 1)
+
+    lin("temb.dense.0", ch, temb_ch)
+    lin("temb.dense.1", temb_ch, temb_ch)
+    conv("conv_in", in_ch, ch, 3)
+
+    res = config.data.image_size
+    in_ch_mult = (1,) + ch_mult
+    nres = len(ch_mult)
+    block_in = None
+    for l in range(nres):
+        block_in = ch * in_ch_mult[l]
+        block_out = ch * ch_mult[l]
+        for b in range(nrb):
+            resblock(f"down.{l}.block.{b}", block_in, block_out)
+            block_in = block_out
+        # the reference registers `down.block` (all blocks) before `down.attn`
+        if res in attn_res:
+            for b in range(nrb):
+                attn(f"down.{l}.attn.{b}", block_out)
+        if l != nres - 1:
+            conv(f"down.{l}.downsample.conv", block_in, block_in, 3)
+            res //= 2
+    resblock("mid.block_1", block_in, block_in)
+    attn("mid.attn_1", block_in)
+    resblock("mid.block_2", block_in, block_in)
+
+    up = {}
+    for l in reversed(range(nres)):
+        entries: "OrderedDict[str, tuple]" = OrderedDict()
+        saved, shapes = shapes, entries
+        block_out = ch * ch_mult[l]
+        skip_in = ch * ch_mult[l]
+        for b in range(nrb + 1):
+            if b == nrb:
+                skip_in = ch * in_ch_mult[l]
+            resblock(f"up.{l}.block.{b}", block_in + skip_in, block_out)
+            block_in = block_out
+        if res in attn_res:
+            for b in range(nrb + 1):
+                attn(f"up.{l}.attn.{b}", block_out)
+        if l != 0:
+            conv(f"up.{l}.upsample.conv", block_in, block_in, 3)
+            res *= 2
+        shapes = saved
+        up[l] = entries
+    for l in range(nres):  # the reference prepends, so state_dict order is up.0, up.1, ...
+        shapes.update(up[l])
+    norm("norm_out", block_in)
+    conv("conv_out", block_in, out_ch, 3)
+    return shapes
+
+
+# ----------------------------------------------------------------------------------------------
+# procedural values
+# ----------------------------------------------------------------------------------------------
+def procedural_tensor(name: str, shape, seed: int = 61) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64((seed ^ zlib.crc32(name.encode())) & 0xFFFFFFFF))
+    z = rng.standard_normal(size=shape, dtype=np.float64)
+    if len(shape) > 1:
+        fan_in = int(np.prod(shape[1:]))
+        w = z / np.sqrt(fan_in)
+    elif name.endswith(".weight"):
+        w = 1.0 + 0.1 * z
+    else:
+        w = 0.1 * z
+    return w.astype(np.float32)
+
+
+def procedural_state_dict(config, seed: int = 61):
+    """OrderedDict name -> torch.float32 CPU tensor for the UNet of `config`."""
+    import torch
+    sd = OrderedDict()
+    for name, shape in unet_param_shapes(config).items():
+        sd[name] = torch.from_numpy(procedural_tensor(name, shape, seed))
+    return sd
+
+
+def synthetic_batch(batch: int, patch_px: int = 256, seed: int = 61):
+    """Synthetic raindrop crops: rainy ~ U[0,1) of shape (B,3,px,px) and the
+    start noise x_T ~ N(0,1) of shape (B,3,px/4,px/4); HFRM output stand-in = rainy (identity).
+    Returned as CPU float32 torch tensors so every box regenerates identical inputs."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    rainy = torch.rand(batch, 3, patch_px, patch_px, generator=g, dtype=torch.float32)
+    x_T = torch.randn(batch, 3, patch_px // 4, patch_px // 4, generator=g, dtype=torch.float32)
+    return rainy, x_T
