@@ -1,0 +1,167 @@
+/*
+ * wavedm.h -- C ABI of libwavedm_hip.so: the MI355X (gfx950) implementation of WaveDM's sampling
+ * hot path: 2-level Haar wavelet-packet DWT/IDWT, the wavelet-domain diffusion
+ * UNet forward, and the per-step DDIM patch gather / scatter-mean / update.
+ *
+ * The reference has no FFI layer (it is pure Python on torch); each entry point
+ * below names the reference function whose device work it replaces.  The reference-side binding
+ * (ctypes) is shown in INTEGRATION.md and implemented in wavedm_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 (WDM_OK) or a negative WDM_E* code and never throws;
+ *     wdm_last_error() gives the message of the last failure on the calling thread;
+ *   - the library never allocates device memory: the caller (torch) owns every buffer including
+ *     the packed-weight buffer and the workspace, and passes raw device pointers;
+ *   - all kernels are enqueued on the `stream` argument (a hipStream_t; pass torch's current
+ *     stream); no call synchronises the device;
+ *   - one wdm_handle per device, one wdm_unet per model; a handle/unet is not thread-safe,
+ *     distinct handles are independent;
+ *   - "NCHW f32" tensors are the reference's layout at the boundary; inside the UNet
+ *     activations are NHWC (channels-last) in the model dtype (WDM_BF16 or WDM_F32).
+ */
+#ifndef WAVEDM_H
+#define WAVEDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDM_ABI_VERSION 1
+
+enum {
+    WDM_OK = 0,
+    WDM_EINVAL = -1,    /* bad argument / unsupported shape */
+    WDM_ENOMEM = -2,    /* caller-provided buffer too small */
+    WDM_EHIP = -3,      /* a HIP runtime call failed */
+    WDM_ESTATE = -4,    /* call order violated (e.g. forward before all params loaded) */
+    WDM_ENOTFOUND = -5  /* unknown parameter name */
+};
+
+enum { WDM_F32 = 0, WDM_BF16 = 1 };
+
+typedef struct wdm_handle wdm_handle;
+typedef struct wdm_unet wdm_unet;
+
+/* ---- library / handle ------------------------------------------------------------------- */
+int wdm_abi_version(void);
+const char* wdm_last_error(void);
+int wdm_create(int device, wdm_handle** out);
+int wdm_destroy(wdm_handle* h);
+
+/* ---- Haar wavelet-packet transform ---------------------------------------------------------
+ * Replaces WaveletTransform.forward, models/wavelet.py:37-49 (scale=2, transpose=True):
+ *   fwd: x (B,3,H,W) NCHW f32  ->  y (B,48,H/4,W/4) NCHW f32, channel = subband*3 + rgb
+ *   inv: y (B,48,h,w)          ->  x (B,3,4h,4w)
+ * H and W must be multiples of 4. */
+int wdm_dwt_fwd(wdm_handle* h, const float* x, float* y, int B, int H, int W, void* stream);
+int wdm_dwt_inv(wdm_handle* h, const float* y, float* x, int B, int hh, int ww, void* stream);
+
+/* ---- layout helpers at the UNet boundary ---------------------------------------------------
+ * A "patch list" is n triples (img, hi, wi) of int32 on the DEVICE: patch k is the p x p window
+ * at (hi, wi) of image `img` of a (NIMG, C, H, W) NCHW f32 tensor.  It restates the reference's
+ * `corners` list (models/ddm_wavelet.py:419) with an explicit image index so that B independent
+ * 64x64 crops (corners = [(0,0)] each) and one stitched image (45 corners) use the same kernels.
+ *
+ * wdm_pack_channels: gather `nch` channels of src (NIMG, nch, H, W) NCHW f32 for every patch into
+ * channels [c_off, c_off+nch) of the NHWC UNet input x96 (n, p, p, 96) of dtype `dtype`.
+ * Replaces crop()+cat at models/ddm_wavelet.py:467-478 (channel order [x_cond 0:48 | x_t 48:51 |
+ * x_other 51:96]). */
+int wdm_pack_channels(wdm_handle* h, const float* src, int nch, int H, int W, const int32_t* patches, int n,
+                      int p, void* x96, int c_total, int c_off, int dtype, void* stream);
+
+/* wdm_ddim_update: scatter-add of the predicted noise patches into the full image in patch-list
+ * order, division by the overlap count, and the eta=0 DDIM update; replaces
+ * models/ddm_wavelet.py:485-502.
+ *   eps      (n, 3, p, p) NCHW f32 : UNet output per patch
+ *   x_t      (NIMG, 3, H, W)       : current sample;  x0_out / x_next_out same shape
+ *   coefficients (host floats, computed by the caller in fp32 like utils/sampling.py:10-13):
+ *     sqrt_1m_at = sqrt(1-abar_t), sqrt_at = sqrt(abar_t), sqrt_at_next, c2 = sqrt(1-abar_next)
+ *   x0 = (x_t - eps*sqrt_1m_at)/sqrt_at ;  x_next = sqrt_at_next*x0 + c2*eps
+ * Pixels covered by no patch get eps = 0/0 = NaN exactly like the reference's division. */
+int wdm_ddim_update(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, const float* x_t,
+                    int nimg, int H, int W, float sqrt_1m_at, float sqrt_at, float sqrt_at_next, float c2,
+                    float* x0_out, float* x_next_out, void* stream);
+
+/* NCHW f32 (B,C,H,W) -> NHWC dtype (B,H,W,C) and back (used by the drop-in model(x, t) call). */
+int wdm_nchw_to_nhwc(wdm_handle* h, const float* src, void* dst, int B, int C, int H, int W, int dtype,
+                     void* stream);
+int wdm_nhwc_to_nchw(wdm_handle* h, const void* src, float* dst, int B, int C, int H, int W, int dtype,
+                     void* stream);
+
+/* ---- UNet ----------------------------------------------------------------------------------
+ * Replaces DiffusionUNet.__init__/forward, models/unet.py:197-307, 346-395 (use_window and
+ * wavelet_in_unet off, as in configs/raindrop_wavelet.yml). */
+typedef struct wdm_unet_config {
+    int ch;                  /* model.ch */
+    int n_levels;            /* len(model.ch_mult), <= 8 */
+    int ch_mult[8];
+    int num_res_blocks;
+    int n_attn_res;          /* len(model.attn_resolutions), <= 8 */
+    int attn_resolutions[8];
+    int in_channels;         /* UNet input channels (96 for raindrop_wavelet.yml, unet.py:212) */
+    int out_ch;              /* 3 */
+    int resolution;          /* data.image_size */
+    int resamp_with_conv;    /* must be 1 */
+    int dtype;               /* WDM_BF16 (throughput) or WDM_F32 (parity mode) */
+} wdm_unet_config;
+
+int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out);
+int wdm_unet_destroy(wdm_unet* u);
+
+/* state_dict enumeration: names/shapes are exactly the reference's state_dict keys */
+int wdm_unet_num_params(const wdm_unet* u);
+int wdm_unet_param_info(const wdm_unet* u, int i, const char** name, int* ndim, int64_t shape[4]);
+
+/* packed weights live in ONE caller-allocated device buffer (so a rank-0 RCCL broadcast of that
+ * buffer is the whole weight distribution step) */
+size_t wdm_unet_packed_bytes(const wdm_unet* u);
+int wdm_unet_set_packed(wdm_unet* u, void* packed, size_t bytes);
+/* repack one fp32 parameter (device pointer, reference layout: conv OIHW, Linear [out,in]) into
+ * the packed buffer, converting to the model dtype */
+int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int64_t numel, void* stream);
+/* mark the packed buffer as complete without per-parameter loads (after a broadcast) */
+int wdm_unet_mark_loaded(wdm_unet* u);
+
+size_t wdm_unet_workspace_bytes(const wdm_unet* u, int B);
+/* x96: (B, R, R, in_channels) NHWC in the model dtype; t: n_t device floats, n_t in {1, B};
+ * eps_out: (B, out_ch, R, R) NCHW f32 */
+int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int B, float* eps_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-block entry points (unit parity tests; same code the UNet executor runs) -----------
+ * Weights are given in the reference layout as fp32 device pointers and packed on the fly into
+ * `scratch`; x / y are NCHW f32 at this test boundary.  See wavedm_amd/csrc/blocks_api.hip. */
+typedef struct wdm_resblock_params {  /* ResnetBlock, models/unet.py:81-138 */
+    int cin, cout;
+    const float *norm1_w, *norm1_b, *conv1_w, *conv1_b, *temb_w, *temb_b;
+    const float *norm2_w, *norm2_b, *conv2_w, *conv2_b, *nin_w, *nin_b; /* nin_* NULL if cin==cout */
+} wdm_resblock_params;
+typedef struct wdm_attn_params {      /* AttnBlock, models/unet.py:141-193 */
+    int c;
+    const float *norm_w, *norm_b, *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *proj_w, *proj_b;
+} wdm_attn_params;
+
+/* x may be the channel concat of two tensors (x0: c0 channels, x1: c1 channels, c1 may be 0) */
+int wdm_resblock_forward(wdm_handle* h, const wdm_resblock_params* p, const float* x0, int c0, const float* x1,
+                         int c1, const float* temb /* (n_t, 512) raw temb, SiLU applied inside */, int n_t,
+                         int temb_ch, int B, int H, int W, float* y, int dtype, void* scratch,
+                         size_t scratch_bytes, void* stream);
+int wdm_attn_forward(wdm_handle* h, const wdm_attn_params* p, const float* x, int B, int H, int W, float* y,
+                     int dtype, void* scratch, size_t scratch_bytes, void* stream);
+/* mode: 0 = conv3x3 s1 p1, 1 = Downsample (pad(0,1,0,1) + conv3x3 s2), 2 = Upsample (nearest x2 +
+ * conv3x3 p1), 3 = conv1x1 */
+int wdm_conv_forward(wdm_handle* h, const float* w, const float* b, int cin, int cout, int mode, const float* x,
+                     int B, int H, int W, float* y, int dtype, void* scratch, size_t scratch_bytes,
+                     void* stream);
+/* timestep embedding + temb MLP (unet.py:10-28, 354-357): t (n_t) -> temb (n_t, 4*ch) */
+int wdm_temb_forward(wdm_handle* h, const float* t, int n_t, int ch, const float* w0, const float* b0,
+                     const float* w1, const float* b1, float* temb_out, void* scratch, size_t scratch_bytes,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEDM_H */

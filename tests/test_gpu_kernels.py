@@ -1,0 +1,181 @@
+"""GPU parity: every kernel / block of the HIP path (called through the C ABI) against the CPU
+oracle on the same seeded inputs and against the committed golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return gpu_util
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import wavedm_oracle
+    return wavedm_oracle
+
+
+# ----------------------------------------------------------------------------------------- DWT / IDWT
+def test_dwt_golden_and_properties(gu, O, golden):
+    from wavedm_amd import WaveletTransform
+    dec, rec = WaveletTransform(scale=2, dec=True), WaveletTransform(scale=2, dec=False)
+    d = golden("dwt.npz")
+    x = torch.from_numpy(d["x"]).cuda()
+    y = dec(x)
+    assert rel_linf(y.cpu(), d["y"]) <= 1e-6
+    assert rel_linf(rec(torch.from_numpy(d["y"]).cuda()).cpu(), d["xr"]) <= 1e-6
+    assert rel_linf(dec(torch.from_numpy(d["x2"]).cuda()).cpu(), d["y2"]) <= 1e-6         # ragged 8x12
+    # integer-exact sub-band bookkeeping: a one-hot 4x4 block lights exactly +-0.25 in channel j*3+c
+    t = golden("tables.npz")
+    for c in range(3):
+        for pq in (0, 5, 10, 15):
+            xi = torch.zeros(1, 3, 4, 4)
+            xi[0, c, pq // 4, pq % 4] = 1.0
+            yi = dec(xi.cuda()).cpu().flatten()
+            for j in range(16):
+                for cc in range(3):
+                    want = 0.25 * float(t["rec4_sign"][j, pq]) if cc == c else 0.0
+                    assert yi[j * 3 + cc].item() == want
+    # full-size properties (BASELINE config 1 input: 64 x 3 x 256 x 256): round trip + linearity + energy
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(64, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    b = (torch.rand(64, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    ya, yb = dec(a), dec(b)
+    assert rel_linf(rec(ya).cpu(), a.cpu()) <= 1e-6
+    assert rel_linf(dec(a + 2 * b).cpu(), (ya + 2 * yb).cpu()) <= 1e-6
+    assert abs(float((ya.double() ** 2).sum() / (a.double() ** 2).sum()) - 1.0) <= 1e-6   # orthonormal basis
+    assert rel_linf(ya[:4].cpu(), O.dwt_fwd(a[:4].cpu())) <= 1e-6
+    # empty batch
+    assert dec(torch.zeros(0, 3, 8, 8).cuda()).shape == (0, 48, 2, 2)
+
+
+# ----------------------------------------------------------------------------------------- convs
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("mode,cin,cout,B,H", [
+    (0, 64, 128, 2, 16), (0, 96, 128, 1, 32), (0, 128, 3, 2, 16), (0, 64, 64, 3, 8), (0, 128, 3, 1, 8),
+    (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16),
+    (3, 64, 128, 2, 16), (3, 160, 64, 3, 8), (3, 384, 128, 1, 32),
+])
+def test_conv_modes(gu, O, dtype, mode, cin, cout, B, H):
+    k = 1 if mode == 3 else 3
+    w = gu.seeded((cout, cin, k, k), 100 + mode) / (cin * k * k) ** 0.5
+    b = gu.seeded((cout,), 200 + mode) * 0.1
+    x = gu.seeded((B, cin, H, H), 300 + mode + H)
+    sd = {"c.conv.weight": w, "c.conv.bias": b, "c.weight": w, "c.bias": b}
+    ref = [lambda: O.conv(sd, "c", x, padding=1), lambda: O.downsample(sd, "c", x), lambda: O.upsample(sd, "c", x),
+           lambda: O.conv(sd, "c", x)][mode]()
+    got = gu.conv(w, b, mode, x, dtype)
+    assert got.shape == ref.shape
+    assert rel_linf(got, ref) <= gu.TOL[dtype], (mode, cin, cout, B, H)
+
+
+# ----------------------------------------------------------------------------------------- blocks vs golden + oracle
+def _resblock_shapes(cin, cout):
+    s = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,),
+         "temb_proj.weight": (cout, 512), "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,),
+         "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    if cin != cout:
+        s.update({"nin_shortcut.weight": (cout, cin, 1, 1), "nin_shortcut.bias": (cout,)})
+    return s
+
+
+def _attn_shapes(c):
+    s = {"norm.weight": (c,), "norm.bias": (c,)}
+    for p in ("q", "k", "v", "proj_out"):
+        s[p + ".weight"] = (c, c, 1, 1)
+        s[p + ".bias"] = (c,)
+    return s
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name,cin,cout,xs,sx,ts,st,split", [
+    ("rb_a", 64, 128, (2, 64, 16, 16), 10, (2, 512), 11, 0),
+    ("rb_b", 128, 128, (2, 128, 8, 8), 12, (1, 512), 13, 0),
+    ("rb_c", 384, 128, (1, 384, 16, 16), 14, (1, 512), 15, 256),      # concat [256 | 128]
+    ("rb_d", 1280, 768, (1, 1280, 8, 8), 16, (1, 512), 17, 768),      # GroupNorm group straddles the concat seam
+])
+def test_resblock_golden(gu, O, golden, dtype, name, cin, cout, xs, sx, ts, st, split):
+    sd = gu.blk_sd(name, _resblock_shapes(cin, cout))
+    x, temb = gu.seeded(xs, sx), gu.seeded(ts, st)
+    x0, x1 = (x, None) if not split else (x[:, :split].contiguous(), x[:, split:].contiguous())
+    got = gu.resblock(sd, name, x0, x1, temb, dtype)
+    want = golden("blocks.npz")[name]
+    assert rel_linf(got, want) <= gu.TOL[dtype]
+    assert rel_linf(got, O.resnet_block(sd, name, x, temb)) <= gu.TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_attn_golden(gu, O, golden, dtype):
+    b = golden("blocks.npz")
+    x = gu.seeded((1, 512, 16, 16), 20)
+    got = gu.attn(gu.blk_sd("at_a", _attn_shapes(512)), "at_a", x, dtype)
+    assert rel_linf(got.flatten()[::5], b["at_a_s5"]) <= gu.TOL[dtype]
+    x = gu.seeded((2, 64, 8, 8), 21)
+    got = gu.attn(gu.blk_sd("at_b", _attn_shapes(64)), "at_b", x, dtype)
+    assert rel_linf(got, b["at_b"]) <= gu.TOL[dtype]
+    x = gu.seeded((1, 768, 8, 8), 22)
+    got = gu.attn(gu.blk_sd("at_c", _attn_shapes(768)), "at_c", x, dtype)
+    assert rel_linf(got, b["at_c"]) <= gu.TOL[dtype]
+
+
+def test_temb(gu, O, golden):
+    from wavedm_amd import procedural as P
+    w0, b0 = torch.from_numpy(P.procedural_tensor("t.0.weight", (512, 128))), torch.from_numpy(P.procedural_tensor("t.0.bias", (512,)))
+    w1, b1 = torch.from_numpy(P.procedural_tensor("t.1.weight", (512, 512))), torch.from_numpy(P.procedural_tensor("t.1.bias", (512,)))
+    t = torch.tensor([0.0, 10.0, 990.0])
+    got = gu.temb(t, 128, w0, b0, w1, b1)
+    e = O.timestep_embedding(t, 128)
+    for i, tt in enumerate((0, 10, 990)):
+        assert rel_linf(e[i:i + 1], golden("blocks.npz")[f"temb_{tt}"]) <= 1e-6
+    want = torch.nn.functional.linear(O.silu(torch.nn.functional.linear(e, w0, b0)), w1, b1)
+    assert rel_linf(got, want) <= 1e-5
+
+
+# ----------------------------------------------------------------------------------------- gather / scatter-mean / DDIM
+def test_patch_gather_scatter_ddim(gu, O):
+    import ctypes as C
+    from wavedm_amd import _lib
+    L, h = _lib.lib(), _lib.handle(0)
+    H, W, p, r = 30, 45, 16, 4
+    corners = O.grid_corners(H, W, p, r)
+    n = len(corners)
+    g = torch.Generator().manual_seed(9)
+    xt = torch.randn(1, 3, H, W, generator=g)
+    cond = torch.randn(1, 48, H, W, generator=g)
+    eps = torch.randn(n, 3, p, p, generator=g)
+    pt = torch.tensor([(0, a, b) for a, b in corners], dtype=torch.int32).cuda()
+    # gather (integer-exact placement: values are copied, fp32 -> fp32)
+    x96 = torch.zeros(n, p, p, 96, device="cuda")
+    _lib.check(L.wdm_pack_channels(h, _lib.ptr(cond.cuda()), 48, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 0, _lib.WDM_F32, _lib.stream_ptr()))
+    _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt.cuda()), 3, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 48, _lib.WDM_F32, _lib.stream_ptr()))
+    got = x96.cpu().permute(0, 3, 1, 2)
+    for k, (hi, wi) in enumerate(corners):
+        assert torch.equal(got[k, :48], cond[0, :, hi:hi + p, wi:wi + p])
+        assert torch.equal(got[k, 48:51], xt[0, :, hi:hi + p, wi:wi + p])
+    # scatter-mean + DDIM update vs the oracle's restatement of ddm_wavelet.py:485-502
+    betas = O.beta_schedule(__import__("wavedm_amd.procedural", fromlist=["x"]).raindrop_wavelet_config())
+    at, an = O.compute_alpha(betas, 500), O.compute_alpha(betas, 400)
+    acc, mask = torch.zeros(1, 3, H, W), torch.zeros(1, 3, H, W)
+    for k, (hi, wi) in enumerate(corners):
+        acc[0, :, hi:hi + p, wi:wi + p] += eps[k]
+        mask[0, :, hi:hi + p, wi:wi + p] += 1
+    et = acc / mask
+    x0w = (xt - et * (1 - at).sqrt()) / at.sqrt()
+    xnw = an.sqrt() * x0w + (1 - an).sqrt() * et
+    x0, xn = torch.empty(1, 3, H, W, device="cuda"), torch.empty(1, 3, H, W, device="cuda")
+    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps.cuda()), _lib.ptr(pt), n, p, _lib.ptr(xt.cuda()), 1, H, W, float((1 - at).sqrt()),
+                                 float(at.sqrt()), float(an.sqrt()), float((1 - an).sqrt()), _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
+    assert rel_linf(x0.cpu(), x0w) <= 1e-6 and rel_linf(xn.cpu(), xnw) <= 1e-6
+    # uncovered pixels -> NaN like the reference's 0/0
+    pt2 = torch.tensor([(0, 0, 0)], dtype=torch.int32).cuda()
+    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps.cuda()), _lib.ptr(pt2), 1, p, _lib.ptr(xt.cuda()), 1, H, W, 0.5, 0.5, 0.5, 0.5,
+                                 _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
+    assert torch.isnan(x0.cpu()[0, 0, H - 1, W - 1]) and not torch.isnan(x0.cpu()[0, 0, 0, 0])

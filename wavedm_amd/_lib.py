@@ -1,0 +1,118 @@
+"""ctypes binding of libwavedm_hip.so (include/wavedm.h).
+
+The HIP library is THE product path: nothing in this package falls back to PyTorch or to the CPU
+oracle.  If the shared object is missing `lib()` raises with the build command."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwavedm_hip.so")
+
+WDM_F32, WDM_BF16 = 0, 1
+DTYPES = {"f32": WDM_F32, "fp32": WDM_F32, "float32": WDM_F32, "bf16": WDM_BF16, "bfloat16": WDM_BF16}
+
+_lib = None
+_handles = {}
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [("ch", C.c_int), ("n_levels", C.c_int), ("ch_mult", C.c_int * 8), ("num_res_blocks", C.c_int),
+                ("n_attn_res", C.c_int), ("attn_resolutions", C.c_int * 8), ("in_channels", C.c_int),
+                ("out_ch", C.c_int), ("resolution", C.c_int), ("resamp_with_conv", C.c_int), ("dtype", C.c_int)]
+
+
+class ResblockParams(C.Structure):
+    _fields_ = [("cin", C.c_int), ("cout", C.c_int)] + [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "conv1_w", "conv1_b", "temb_w", "temb_b", "norm2_w", "norm2_b", "conv2_w", "conv2_b",
+        "nin_w", "nin_b")]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("c", C.c_int)] + [(n, C.c_void_p) for n in (
+        "norm_w", "norm_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj_w", "proj_b")]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"wavedm_amd: HIP library not built ({LIB_PATH} missing). Build it with "
+            f"`make -C {os.path.join(_HERE, 'csrc')}` or `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU / PyTorch fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+    sig = {
+        "wdm_abi_version": (i, []),
+        "wdm_last_error": (C.c_char_p, []),
+        "wdm_create": (i, [i, C.POINTER(vp)]),
+        "wdm_destroy": (i, [vp]),
+        "wdm_dwt_fwd": (i, [vp, vp, vp, i, i, i, vp]),
+        "wdm_dwt_inv": (i, [vp, vp, vp, i, i, i, vp]),
+        "wdm_pack_channels": (i, [vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]),
+        "wdm_ddim_update": (i, [vp, vp, vp, i, i, vp, i, i, i, f, f, f, f, vp, vp, vp]),
+        "wdm_nchw_to_nhwc": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+        "wdm_nhwc_to_nchw": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+        "wdm_unet_create": (i, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),
+        "wdm_unet_destroy": (i, [vp]),
+        "wdm_unet_num_params": (i, [vp]),
+        "wdm_unet_param_info": (i, [vp, i, C.POINTER(C.c_char_p), C.POINTER(i), C.POINTER(i64 * 4)]),
+        "wdm_unet_packed_bytes": (sz, [vp]),
+        "wdm_unet_set_packed": (i, [vp, vp, sz]),
+        "wdm_unet_load_param": (i, [vp, C.c_char_p, vp, i64, vp]),
+        "wdm_unet_mark_loaded": (i, [vp]),
+        "wdm_unet_workspace_bytes": (sz, [vp, i]),
+        "wdm_unet_forward": (i, [vp, vp, vp, i, i, vp, vp, sz, vp]),
+        "wdm_resblock_forward": (i, [vp, C.POINTER(ResblockParams), vp, i, vp, i, vp, i, i, i, i, i, vp, i, vp, sz, vp]),
+        "wdm_attn_forward": (i, [vp, C.POINTER(AttnParams), vp, i, i, i, vp, i, vp, sz, vp]),
+        "wdm_conv_forward": (i, [vp, vp, vp, i, i, i, vp, i, i, i, vp, i, vp, sz, vp]),
+        "wdm_temb_forward": (i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = header / library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if L.wdm_abi_version() != 1:
+        raise RuntimeError("wavedm_amd: libwavedm_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "wdm_dwt_fwd", "wdm_dwt_inv",
+            "wdm_pack_channels", "wdm_ddim_update", "wdm_nchw_to_nhwc", "wdm_nhwc_to_nchw", "wdm_unet_create",
+            "wdm_unet_destroy", "wdm_unet_num_params", "wdm_unet_param_info", "wdm_unet_packed_bytes",
+            "wdm_unet_set_packed", "wdm_unet_load_param", "wdm_unet_mark_loaded", "wdm_unet_workspace_bytes",
+            "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward"]
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libwavedm_hip: error {rc}: {lib().wdm_last_error().decode(errors='replace')}")
+
+
+def handle(device_index: int):
+    """One wdm_handle per device (created on first use)."""
+    if device_index not in _handles:
+        h = C.c_void_p()
+        check(lib().wdm_create(int(device_index), C.byref(h)))
+        _handles[device_index] = h
+    return _handles[device_index]
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda_f32(t, name):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{name}: expected a float32 tensor on the GPU (got {getattr(t, 'dtype', type(t))} on "
+                        f"{getattr(t, 'device', '?')}); wavedm_amd has no CPU path")
+    return t.contiguous()

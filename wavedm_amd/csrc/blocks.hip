@@ -1,0 +1,203 @@
+// Host-side composition of the UNet's building blocks out of the fused kernels:
+//   ResnetBlock (unet.py:119-138), AttnBlock (unet.py:168-193), Downsample / Upsample convs.
+// The same functions back the whole-UNet executor (unet.hip) and the per-block C entry points used by the
+// parity tests (api.hip).  In "dry" mode nothing is launched; only the arena is exercised so that the
+// executor can report its exact workspace requirement.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace wdm {
+
+// ---- error message (thread local) ------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ---- arena -----------------------------------------------------------------------------------
+void* Arena::alloc(size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    for (size_t i = 0; i < free_.size(); ++i) {
+        if (free_[i].len >= bytes) {
+            const size_t off = free_[i].off;
+            free_[i].off += bytes;
+            free_[i].len -= bytes;
+            if (free_[i].len == 0) free_.erase(free_.begin() + i);
+            used_.push_back({off, bytes});
+            peak_ = std::max(peak_, off + bytes);
+            // dry mode hands out fake, distinct, non-null addresses
+            return base_ ? (void*)(base_ + off) : (void*)(uintptr_t)(off + 4096);
+        }
+    }
+    failed_ = true;
+    return nullptr;
+}
+void Arena::free(void* p) {
+    if (!p) return;
+    const size_t off = base_ ? (size_t)((char*)p - base_) : (size_t)((uintptr_t)p - 4096);
+    for (size_t i = 0; i < used_.size(); ++i) {
+        if (used_[i].off == off) {
+            Blk b = used_[i];
+            used_.erase(used_.begin() + i);
+            auto it = std::lower_bound(free_.begin(), free_.end(), b, [](const Blk& a, const Blk& c) { return a.off < c.off; });
+            it = free_.insert(it, b);
+            // coalesce with neighbours
+            if (it + 1 != free_.end() && it->off + it->len == (it + 1)->off) { it->len += (it + 1)->len; free_.erase(it + 1); }
+            if (it != free_.begin() && (it - 1)->off + (it - 1)->len == it->off) { (it - 1)->len += it->len; free_.erase(it); }
+            return;
+        }
+    }
+}
+
+int alloc_tens(Ctx& c, int C, int H, int W, Tens* t) {
+    t->C = C; t->H = H; t->W = W; t->xs = C;
+    t->p = c.ar->alloc((size_t)c.B * H * W * C * dsize(c.dtype));
+    if (!t->p) WDM_FAIL(WDM_ENOMEM, "workspace too small (tensor %dx%dx%dx%d)", c.B, H, W, C);
+    return WDM_OK;
+}
+void free_tens(Ctx& c, Tens& t) { c.ar->free(t.p); t.p = nullptr; }
+
+static int alloc_f32(Ctx& c, size_t n, float** p) {
+    *p = (float*)c.ar->alloc(n * sizeof(float));
+    if (!*p) WDM_FAIL(WDM_ENOMEM, "workspace too small (%zu floats)", n);
+    return WDM_OK;
+}
+
+int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
+    return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : launch_conv_f32(a, mode, s);
+}
+
+// ---- one fused convolution ---------------------------------------------------------------------
+// out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
+int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
+             int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext) {
+    const int Cin = x0.C + (x1 ? x1->C : 0);
+    if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
+    if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
+    int Ho = x0.H, Wo = x0.W;
+    if (mode == MODE_S2) { Ho = x0.H / 2; Wo = x0.W / 2; }
+    if (mode == MODE_UPS) { Ho = x0.H * 2; Wo = x0.W * 2; }
+    void* y = y_ext;
+    if (!y_ext) {
+        WDM_TRY(alloc_tens(c, w.cout, Ho, Wo, out));
+        y = out->p;
+        y_mode = Y_NHWC;
+    }
+    if (c.dry) return WDM_OK;
+    ConvArgs a{};
+    a.x0 = x0.p; a.x1 = x1 ? x1->p : nullptr;
+    a.C0 = x0.C; a.C1 = x1 ? x1->C : 0;
+    a.xs0 = x0.xs; a.xs1 = x1 ? x1->xs : 0;
+    a.B = c.B; a.Hin = x0.H; a.Win = x0.W; a.Hout = Ho; a.Wout = Wo;
+    a.Cin = Cin; a.Cout = w.cout;
+    a.w = w.w; a.w_tap_stride = (long long)w.rows_pad * w.cin; a.w_img_stride = 0; a.w_row_stride = w.cin; a.w_rows = w.rows_pad;
+    a.bias = w.b; a.alpha = 1.0f;
+    a.pro = scale ? 1 : 0; a.scale = scale; a.shift = shift;
+    a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
+    a.res = res ? res->p : nullptr; a.res_s = res ? res->xs : 0;
+    a.y = y; a.y_mode = y_mode; a.y_s = w.cout;
+    return launch_conv(a, mode, c.dtype, c.s);
+}
+
+// GroupNorm statistics of [x0 | x1] -> scale/shift (allocated here, caller frees both)
+static int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, float** scale, float** shift) {
+    const int C = x0.C + (x1 ? x1->C : 0);
+    const int HW = x0.H * x0.W;
+    float* partial = nullptr;
+    WDM_TRY(alloc_f32(c, (size_t)c.B * C, scale));
+    WDM_TRY(alloc_f32(c, (size_t)c.B * C, shift));
+    WDM_TRY(alloc_f32(c, gn_partial_bytes(c.B, HW, C) / sizeof(float), &partial));
+    int rc = WDM_OK;
+    if (!c.dry) rc = k_gn_scale_shift(x0, x1, c.B, nw, 1e-6f, partial, *scale, *shift, c.dtype, c.s);
+    c.ar->free(partial);   // stream-ordered: later kernels that reuse this memory run after the finalize kernel
+    return rc;
+}
+
+// ---- ResnetBlock: GN -> SiLU -> conv3x3 (+temb) -> GN -> SiLU -> conv3x3 -> + (x | nin_shortcut(x)) -------------
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out) {
+    const int Cin = x0.C + (x1 ? x1->C : 0);
+    if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
+    if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
+    float *sc1, *sh1, *sc2, *sh2;
+    Tens t1, sct;
+    WDM_TRY(run_gn(c, w.n1, x0, x1, &sc1, &sh1));
+    WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr));
+    c.ar->free(sc1); c.ar->free(sh1);
+    WDM_TRY(run_gn(c, w.n2, t1, nullptr, &sc2, &sh2));
+    const Tens* res = &x0;
+    if (w.has_nin) {
+        WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
+        res = &sct;
+    }
+    WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr));
+    c.ar->free(sc2); c.ar->free(sh2);
+    free_tens(c, t1);
+    if (w.has_nin) free_tens(c, sct);
+    return WDM_OK;
+}
+
+// ---- AttnBlock: GN -> q,k,v 1x1 -> softmax(q^T k * C^-1/2) -> v.w^T -> proj_out 1x1 -> + x ----------------------
+// All four contractions run on the conv kernel: Q.K^T and P.V are 1x1 convolutions whose "weights" are the
+// image's own K (rows = keys) and V^T (rows = channels; produced by storing the v projection channel-major).
+int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
+    const int C = w.c, N = x.H * x.W;
+    if (x.C != C) WDM_FAIL(WDM_EINVAL, "attn: input has %d channels, block expects %d", x.C, C);
+    if (N % 64 || N > 512) WDM_FAIL(WDM_EINVAL, "attn: %d tokens unsupported (multiple of 64, <= 512)", N);
+    const size_t es = dsize(c.dtype);
+    float *sc, *sh;
+    WDM_TRY(run_gn(c, w.n, x, nullptr, &sc, &sh));
+    Tens hn;
+    WDM_TRY(alloc_tens(c, C, x.H, x.W, &hn));
+    if (!c.dry) WDM_TRY(k_gn_apply(x, c.B, sc, sh, hn.p, c.dtype, c.s));
+    c.ar->free(sc); c.ar->free(sh);
+
+    Tens qk;
+    WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));   // [B][N][2C]
+    void* vT = c.ar->alloc((size_t)c.B * C * N * es);                                                               // [B][C][N]
+    if (!vT) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention V^T)");
+    { Tens dummy; WDM_TRY(run_conv(c, w.v, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &dummy, Y_NCHW, vT)); }
+    free_tens(c, hn);
+
+    float* S = nullptr;
+    WDM_TRY(alloc_f32(c, (size_t)c.B * N * N, &S));
+    void* P = c.ar->alloc((size_t)c.B * N * N * es);
+    if (!P) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention P)");
+    Tens o;
+    WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
+    if (!c.dry) {
+        ConvArgs a{};
+        // S[b][i][j] = C^-1/2 * sum_c q[b][i][c] k[b][j][c]
+        a.x0 = qk.p; a.C0 = C; a.xs0 = 2 * C; a.C1 = 0;
+        a.B = c.B; a.Hin = a.Hout = x.H; a.Win = a.Wout = x.W;
+        a.Cin = C; a.Cout = N;
+        a.w = (const char*)qk.p + (size_t)C * es; a.w_tap_stride = 0; a.w_img_stride = (long long)N * 2 * C; a.w_row_stride = 2 * C; a.w_rows = N;
+        a.alpha = (float)std::pow((double)C, -0.5);
+        a.y = S; a.y_mode = Y_NHWC_F32; a.y_s = N;
+        WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
+        WDM_TRY(k_softmax_rows(S, P, (long long)c.B * N, N, c.dtype, c.s));
+        // O[b][i][c] = sum_j P[b][i][j] V^T[b][c][j]
+        ConvArgs p{};
+        p.x0 = P; p.C0 = N; p.xs0 = N; p.C1 = 0;
+        p.B = c.B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
+        p.Cin = N; p.Cout = C;
+        p.w = vT; p.w_tap_stride = 0; p.w_img_stride = (long long)C * N; p.w_row_stride = N; p.w_rows = C;
+        p.alpha = 1.0f;
+        p.y = o.p; p.y_mode = Y_NHWC; p.y_s = C;
+        WDM_TRY(launch_conv(p, MODE_P1, c.dtype, c.s));
+    }
+    c.ar->free(S); c.ar->free(P); c.ar->free(vT);
+    free_tens(c, qk);
+    WDM_TRY(run_conv(c, w.proj, MODE_P1, o, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr));
+    free_tens(c, o);
+    return WDM_OK;
+}
+
+}  // namespace wdm

@@ -1,0 +1,144 @@
+// Internal declarations shared by the translation units of libwavedm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wavedm.h"
+#include "conv_kernel.h"
+
+namespace wdm {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define WDM_FAIL(code, ...)        \
+    do {                           \
+        wdm::set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+#define WDM_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) WDM_FAIL(WDM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+#define WDM_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != WDM_OK) return rc__; \
+    } while (0)
+
+inline size_t dsize(int dtype) { return dtype == WDM_BF16 ? 2 : 4; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- deterministic first-fit arena over a caller-provided buffer -----------------------------
+// In "dry" mode (base == nullptr) it only tracks the high-water mark; the real run repeats the same
+// alloc/free sequence, so it needs exactly that many bytes.
+class Arena {
+   public:
+    Arena(void* base, size_t cap) : base_((char*)base), cap_(cap) { free_.push_back({0, cap_}); }
+    static Arena dry() { return Arena(nullptr, (size_t)1 << 60); }
+    void* alloc(size_t bytes);
+    void free(void* p);
+    size_t peak() const { return peak_; }
+    bool failed() const { return failed_; }
+    bool is_dry() const { return base_ == nullptr; }
+
+   private:
+    struct Blk { size_t off, len; };
+    char* base_;
+    size_t cap_;
+    size_t peak_ = 0;
+    bool failed_ = false;
+    std::vector<Blk> free_;   // sorted by offset
+    std::vector<Blk> used_;
+};
+
+// ---- tensors inside the executor: NHWC, model dtype, batch implicit ---------------------------
+struct Tens {
+    void* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    int xs = 0;   // pixel stride in elements
+};
+
+struct Ctx {
+    hipStream_t s;
+    int dtype;
+    int B;
+    Arena* ar;
+    bool dry;     // no launches, only arena accounting
+};
+
+// ---- packed parameter views (device pointers) -------------------------------------------------
+struct ConvW {
+    const void* w = nullptr;   // [taps][rows_pad][cin] model dtype
+    const float* b = nullptr;  // [cout]
+    int cin = 0, cout = 0, k = 1, rows_pad = 0;
+};
+struct NormW {
+    const float* g = nullptr;
+    const float* b = nullptr;
+    int c = 0;
+};
+struct ResW {
+    int cin = 0, cout = 0;
+    NormW n1, n2;
+    ConvW c1, c2, nin;
+    bool has_nin = false;
+    const float* temb = nullptr;   // [n_t][temb_ld] projected temb rows for this block (already + bias)
+    int temb_ld = 0;
+    int temb_per_image = 0;
+};
+struct AttnW {
+    int c = 0;
+    NormW n;
+    ConvW qk;     // fused: rows [0,C) = q, rows [C,2C) = k
+    ConvW v, proj;
+};
+
+inline int conv_rows_pad(int cout) { return cout <= 16 ? 16 : (int)align_up((size_t)cout, 64); }
+inline size_t conv_packed_bytes(int cin, int cout, int k, int dtype) {
+    return (size_t)k * k * conv_rows_pad(cout) * cin * dsize(dtype);
+}
+
+// ---- kernels (elementwise.hip) ---------------------------------------------------------------
+int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s);
+int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s);
+int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96,
+                    int c_total, int c_off, int dtype, hipStream_t s);
+int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W,
+                  float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s);
+int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
+int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
+// GroupNorm(32, eps) statistics of the channel concat [x0 | x1] -> per-(image, channel) scale/shift
+size_t gn_partial_bytes(int B, int HW, int C);
+int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale,
+                     float* shift, int dtype, hipStream_t s);
+int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s);
+int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s);
+int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream_t s);
+// out[n][o] = post( W[o][:] . pre(in[n][:]) + b[o] );  act: 0 none, 1 SiLU on input, 2 SiLU on output
+int k_linear(const float* in, int n, int k, const float* W, const float* b, int o, float* out, int act, hipStream_t s);
+// weight packing: OIHW f32 -> [tap][rows_pad][cin] dtype, written at row offset `row_off` of a `rows_total` matrix
+// rows [row_off + cout, rows_total) are zero-filled when zero_tail != 0
+int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail,
+                int dtype, hipStream_t s);
+int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
+
+// ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
+int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
+
+// ---- blocks (blocks.hip) ----------------------------------------------------------------------
+int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
+             const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext);
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
+int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);
+int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);
+void free_tens(Ctx& c, Tens& t);
+
+}  // namespace wdm
+
+struct wdm_handle {
+    int device;
+};

@@ -1,0 +1,405 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X) -- the kernel that carries >98 % of the
+// UNet's FLOPs (conv3x3 91 %, conv1x1 8 %, attention QK^T / PV 1 %).
+//
+// One kernel template covers
+//   MODE_S1  conv3x3 stride 1 pad 1            (ResnetBlock conv1/conv2, conv_in, conv_out; unet.py:91,100,233,303)
+//   MODE_S2  pad(0,1,0,1) + conv3x3 stride 2    (Downsample, unet.py:71-78)
+//   MODE_UPS nearest x2 + conv3x3 pad 1         (Upsample, unet.py:51-56; the upsample is folded into the LDS
+//                                                read address, the x2 tensor is never materialised)
+//   MODE_P1  conv1x1 / plain GEMM               (nin_shortcut, q/k/v/proj_out, and the attention products
+//                                                Q.K^T and P.V with per-image "weights"; unet.py:113,147-189)
+// with, fused in:
+//   * channel concat of two inputs (torch.cat([h, skip]) at unet.py:380 is never materialised),
+//   * GroupNorm-apply + SiLU on the A operand while it is staged into LDS (x*scale[b,c]+shift[b,c], then
+//     x*sigmoid(x)); zero padding is applied AFTER the activation like the reference,
+//   * epilogue: alpha*acc + bias[n] + temb[b,n] + residual, store as NHWC / NCHW in bf16 or f32.
+//
+// GEMM view: M = output pixels (a TH x TW patch of NI images per workgroup), N = output channels,
+// K = taps x Cin.  Activations are NHWC so the K (channel) axis is contiguous for both operands
+// (weights are packed [tap][cout][cin]): every MFMA fragment is one 16-byte LDS read per lane.
+//
+// LDS image (both operands):   [k-unit (4)][row slot][16 bytes]
+//   a "unit" is 16 bytes of consecutive channels (8 bf16 / 4 f32); lane l of a wave reads unit (l>>4) of row
+//   (l&15) -> the 16 lanes of a ds_read_b128 service group touch 16 consecutive 16-byte slots: conflict-free.
+//   The unit planes are padded to a multiple of 16 slots so every unit has the same bank phase.
+//   bf16: one v_mfma_f32_16x16x32_bf16 consumes the 4 units (K = 32);  f32 (parity mode): four
+//   v_mfma_f32_16x16x4_f32, MFMA j taking element j of every unit (K = 16) -- exact fp32 FMA chains.
+//
+// Pipeline per K stage (one 32/16-channel slab x all 9 taps, or 4 slabs for 1x1):
+//   barrier | registers -> LDS (A transform here) | barrier | issue global loads of the NEXT stage into
+//   registers | MFMAs of this stage from LDS.   Global latency hides under the MFMAs; two workgroups per CU
+//   (<= 58 KB LDS each for the main configs) overlap one's LDS-write phase with the other's MFMA phase.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wdm {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned short bf16_raw;
+
+enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UPS = 2, MODE_P1 = 3 };
+enum { Y_NHWC = 0, Y_NCHW = 1, Y_NCHW_F32 = 2, Y_NHWC_F32 = 3 };
+
+struct ConvArgs {
+    const void* x0;
+    const void* x1;
+    int C0, C1;            // channels taken from x0 / x1 (Cin = C0 + C1, C1 == 0: single input)
+    int xs0, xs1;          // pixel stride of x0 / x1 in elements (>= C0 / C1)
+    int B, Hin, Win, Hout, Wout;
+    int Cin, Cout;
+    const void* w;         // [tap][row][cin] (row = output channel), model dtype
+    long long w_tap_stride, w_img_stride;  // elements; w_img_stride != 0: per-image weights (attention)
+    int w_row_stride;      // elements
+    int w_rows;            // rows that exist in memory (rows >= w_rows read as zero)
+    const float* bias;     // [Cout] or nullptr
+    float alpha;           // accumulator scale (attention: C^-0.5), 1 otherwise
+    int pro;               // 0: none, 1: x*scale+shift then SiLU  (MODE_S1 only)
+    const float* scale;    // [B][Cin]
+    const float* shift;    // [B][Cin]
+    const float* temb;     // [n_t][temb_ld] or nullptr, added per (image, n)
+    int temb_ld;
+    int temb_per_image;    // 1: row = image index, 0: row 0 for every image
+    const void* res;       // residual, NHWC model dtype, pixel stride res_s; or nullptr
+    int res_s;
+    void* y;
+    int y_mode;            // Y_*
+    int y_s;               // NHWC pixel stride of y in elements
+    int mtiles, ntiles;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) { return __builtin_bit_cast(bf16_raw, (__bf16)f); }
+
+template <typename T> struct TI;
+template <> struct TI<float> {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+    __device__ static __forceinline__ float ld(const void* p, long long i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void st(void* p, long long i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct TI<__bf16> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        uint4 u;
+        u.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+        u.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+        u.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+        return u;
+    }
+    __device__ static __forceinline__ float ld(const void* p, long long i) { return bf16_to_f32(((const bf16_raw*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, long long i, float v) { ((bf16_raw*)p)[i] = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float silu_f(float v) {
+    // x * sigmoid(x) = x / (1 + e^-x)   (unet.py:31-33)
+    return v / (1.0f + __expf(-v));
+}
+
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<__bf16>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compile-time geometry of one kernel configuration
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+struct ConvCfg {
+    static constexpr int NTHREADS = 256;
+    static constexpr int VEC = TI<T>::VEC;
+    static constexpr int NU = 4;                 // 16-byte k-units per slab
+    static constexpr int BK = NU * VEC;          // channels per slab: 32 (bf16) / 16 (f32)
+    static constexpr int M = TH * TW * NI;
+    static constexpr int BN = 16 * WN * WAVES_N;
+    static constexpr int NSUB = (MODE == MODE_P1) ? 4 : 9;   // B sub-blocks per stage (taps, or slabs for 1x1)
+    static constexpr int NSUBA = (MODE == MODE_P1) ? 4 : 1;  // A sub-planes per stage
+    static constexpr int PH = MODE == MODE_S1 ? TH + 2 : MODE == MODE_S2 ? 2 * TH + 1 : MODE == MODE_UPS ? TH / 2 + 2 : TH;
+    static constexpr int PW = MODE == MODE_S1 ? TW + 2 : MODE == MODE_S2 ? 2 * TW + 1 : MODE == MODE_UPS ? TW / 2 + 2 : TW;
+    // row stride in slots: for 8-wide tiles a 16-row MFMA group spans two image rows; stride == 8 (mod 16)
+    // keeps its 16 slots distinct modulo 16
+    static constexpr int RS = (TW == 8 && MODE == MODE_S1) ? 24 : PW;
+    static constexpr int NPIX = PH * PW;
+    static constexpr int PLANE_IMG = PH * RS;
+    static constexpr int PLANE = ((NI * PLANE_IMG + 15) / 16) * 16;
+    static constexpr int A_BYTES = NSUBA * NU * PLANE * 16;
+    static constexpr int B_BYTES = NSUB * NU * BN * 16;
+    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_IPI = (NSUBA * NPIX * NU + NTHREADS - 1) / NTHREADS;   // A items per thread per image
+    static constexpr int B_IPT = (NSUB * BN * NU + NTHREADS - 1) / NTHREADS;      // B items per thread
+    static constexpr bool PREFETCH = (MODE != MODE_S2);   // S2 tiles stage 4x the pixels: keep registers low
+    static_assert(M == 16 * WM * WAVES_M, "tile M mismatch");
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(NI == 1 || (MODE == MODE_S1 || MODE == MODE_P1), "multi-image tiles: s1 / 1x1 only");
+};
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
+    using C = ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
+    constexpr int VEC = C::VEC, NU = C::NU, BK = C::BK, BN = C::BN;
+    constexpr int NSUB = C::NSUB, NSUBA = C::NSUBA, PW = C::PW, RS = C::RS, NPIX = C::NPIX;
+    constexpr int PLANE = C::PLANE, PLANE_IMG = C::PLANE_IMG, A_BYTES = C::A_BYTES;
+    constexpr int A_IPI = C::A_IPI, B_IPT = C::B_IPT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    // ---- workgroup -> (M tile, N tile).  Consecutive workgroups on one XCD (id % 8 is the XCD the dispatcher
+    // picks) walk the N tiles of the same M tile, so the A tile is re-read from that XCD's L2.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int nt = seq % a.ntiles;
+    const int mt = (seq / a.ntiles) * 8 + xcd;
+    if (mt >= a.mtiles) return;
+    const int n0 = nt * BN;
+
+    int img0, oy0, ox0;
+    if (NI == 1) {
+        const int twn = a.Wout / TW;
+        const int tpi = (a.Hout / TH) * twn;
+        img0 = mt / tpi;
+        const int t = mt - img0 * tpi;
+        oy0 = (t / twn) * TH;
+        ox0 = (t % twn) * TW;
+    } else {
+        img0 = mt * NI; oy0 = 0; ox0 = 0;
+    }
+    // origin of the staged input region in source coordinates
+    const int iy0 = MODE == MODE_S1 ? oy0 - 1 : MODE == MODE_S2 ? 2 * oy0 : MODE == MODE_UPS ? (oy0 >> 1) - 1 : oy0;
+    const int ix0 = MODE == MODE_S1 ? ox0 - 1 : MODE == MODE_S2 ? 2 * ox0 : MODE == MODE_UPS ? (ox0 >> 1) - 1 : ox0;
+
+    // ---- per-lane fragment addresses (bytes into smem)
+    int a_addr[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = (wave_m * WM + i) * 16 + (lane & 15);
+        const int img = m / (TH * TW), r = m % (TH * TW);
+        const int ly = r / TW, lx = r % TW;
+        int slot;
+        if (MODE == MODE_S2) slot = img * PLANE_IMG + 2 * ly * RS + 2 * lx;
+        else if (MODE == MODE_UPS) slot = (ly << 8) | lx;      // resolved per tap below
+        else slot = img * PLANE_IMG + ly * RS + lx;
+        a_addr[i] = (MODE == MODE_UPS) ? slot : ((lane >> 4) * PLANE + slot) * 16;
+    }
+    int b_addr[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+        b_addr[j] = A_BYTES + ((lane >> 4) * BN + (wave_n * WN + j) * 16 + (lane & 15)) * 16;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging registers
+    uint4 ra[NI][A_IPI];
+    uint4 rb[B_IPT];
+    unsigned inb_mask = 0;                 // bit (img*A_IPI + i): item lies inside the image (transform applies)
+    float sc[NI][VEC], sh[NI][VEC];
+    static_assert(NI * A_IPI <= 32, "inb_mask too small");
+
+    const int unit = tid & (NU - 1);
+    const int nchunks = a.Cin / BK;                                   // slabs
+    const int nstages = (MODE == MODE_P1) ? (nchunks + NSUB - 1) / NSUB : nchunks;
+    const int wimg = (a.w_img_stride != 0) ? img0 : 0;
+    const T* wbase = (const T*)a.w + (long long)wimg * a.w_img_stride;
+
+    auto load_stage = [&](int st) __attribute__((always_inline)) {
+        const int cbase = (MODE == MODE_P1) ? st * NSUB * BK : st * BK;
+        // ---- A items
+#pragma unroll
+        for (int im = 0; im < NI; ++im) {
+            const int img_g = img0 + im;
+#pragma unroll
+            for (int i = 0; i < A_IPI; ++i) {
+                const int pq = (tid >> 2) + i * (C::NTHREADS / NU);
+                const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
+                const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
+                const int hy = q / PW, hx = q - hy * PW;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const int c = cbase + sub * BK + unit * VEC;
+                bool ok = (pq < NSUBA * NPIX) && (img_g < a.B) && (c < a.Cin) &&
+                          (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) {
+                    const long long gp = ((long long)img_g * a.Hin + iy) * a.Win + ix;
+                    const T* src = (c < a.C0) ? (const T*)a.x0 + gp * a.xs0 + c : (const T*)a.x1 + gp * a.xs1 + (c - a.C0);
+                    v = *(const uint4*)src;
+                }
+                ra[im][i] = v;
+                const unsigned bit = 1u << (im * A_IPI + i);
+                inb_mask = ok ? (inb_mask | bit) : (inb_mask & ~bit);
+            }
+            if (MODE == MODE_S1) {
+                if (a.pro) {
+                    const int c = cbase + unit * VEC;
+                    const int ig = img_g < a.B ? img_g : a.B - 1;
+                    const float* ps = a.scale + (long long)ig * a.Cin + c;
+                    const float* pf = a.shift + (long long)ig * a.Cin + c;
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) {
+                        const float4 s4 = *(const float4*)(ps + e), f4 = *(const float4*)(pf + e);
+                        sc[im][e] = s4.x; sc[im][e + 1] = s4.y; sc[im][e + 2] = s4.z; sc[im][e + 3] = s4.w;
+                        sh[im][e] = f4.x; sh[im][e + 1] = f4.y; sh[im][e + 2] = f4.z; sh[im][e + 3] = f4.w;
+                    }
+                }
+            }
+        }
+        // ---- B items
+#pragma unroll
+        for (int i = 0; i < B_IPT; ++i) {
+            const int rn = (tid >> 2) + i * (C::NTHREADS / NU);
+            const int sub = rn / BN, n = rn % BN;
+            const int c = (MODE == MODE_P1) ? cbase + sub * BK + unit * VEC : cbase + unit * VEC;
+            const int tap = (MODE == MODE_P1) ? 0 : sub;
+            const int row = n0 + n;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (sub < NSUB && c < a.Cin && row < a.w_rows)
+                v = *(const uint4*)(wbase + (long long)tap * a.w_tap_stride + (long long)row * a.w_row_stride + c);
+            rb[i] = v;
+        }
+    };
+
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int im = 0; im < NI; ++im) {
+#pragma unroll
+            for (int i = 0; i < A_IPI; ++i) {
+                const int pq = (tid >> 2) + i * (C::NTHREADS / NU);
+                if (pq < NSUBA * NPIX) {
+                    const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
+                    const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
+                    const int hy = q / PW, hx = q - hy * PW;
+                    uint4 v = ra[im][i];
+                    if (MODE == MODE_S1) {
+                        if (a.pro && ((inb_mask >> (im * A_IPI + i)) & 1u)) {
+                            float f[VEC];
+                            TI<T>::unpack(v, f);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) f[e] = silu_f(f[e] * sc[im][e] + sh[im][e]);
+                            v = TI<T>::pack(f);
+                        }
+                    }
+                    const int off = (((sub * NU + unit) * PLANE) + im * PLANE_IMG + hy * RS + hx) * 16;
+                    *(uint4*)(smem + off) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IPT; ++i) {
+            const int rn = (tid >> 2) + i * (C::NTHREADS / NU);
+            const int sub = rn / BN, n = rn % BN;
+            if (sub < NSUB) *(uint4*)(smem + A_BYTES + (((sub * NU + unit) * BN) + n) * 16) = rb[i];
+        }
+    };
+
+    auto compute_stage = [&](int st) __attribute__((always_inline)) {
+        int nsub = NSUB;
+        if (MODE == MODE_P1) { const int rem = nchunks - st * NSUB; nsub = rem < NSUB ? rem : NSUB; }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            if (MODE == MODE_P1 && s >= nsub) break;
+            uint4 af[WM], bfr[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                int off;
+                if (MODE == MODE_P1) off = a_addr[i] + s * NU * PLANE * 16;
+                else if (MODE == MODE_UPS) {
+                    const int dy = s / 3, dx = s % 3;
+                    const int ly = a_addr[i] >> 8, lx = a_addr[i] & 255;
+                    off = ((lane >> 4) * PLANE + ((ly + dy + 1) >> 1) * RS + ((lx + dx + 1) >> 1)) * 16;
+                } else {
+                    const int dy = s / 3, dx = s % 3;
+                    off = a_addr[i] + (dy * RS + dx) * 16;
+                }
+                af[i] = *(const uint4*)(smem + off);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(smem + b_addr[j] + s * NU * BN * 16);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+        }
+    };
+
+    // ---- main loop
+    if (C::PREFETCH) load_stage(0);
+    for (int st = 0; st < nstages; ++st) {
+        if (!C::PREFETCH) load_stage(st);
+        __syncthreads();                  // everyone finished reading the previous stage
+        store_stage();
+        __syncthreads();
+        if (C::PREFETCH && st + 1 < nstages) load_stage(st + 1);
+        compute_stage(st);
+    }
+
+    // ---- epilogue
+    const int ncol = lane & 15;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + (wave_n * WN + j) * 16 + ncol;
+        const bool nok = n < a.Cout;
+        const float bj = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wave_m * WM + i) * 16 + (lane >> 4) * 4 + r;
+                const int img = m / (TH * TW), rr = m % (TH * TW);
+                const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
+                const int img_g = img0 + img;
+                if (!nok || img_g >= a.B) continue;
+                float v = acc[i][j][r] * a.alpha + bj;
+                if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
+                const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+                if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
+                if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
+                else if (a.y_mode == Y_NHWC_F32) ((float*)a.y)[opix * a.y_s + n] = v;
+                else {
+                    const long long o = (((long long)img_g * a.Cout + n) * a.Hout + oy) * a.Wout + ox;
+                    if (a.y_mode == Y_NCHW) TI<T>::st(a.y, o, v);
+                    else ((float*)a.y)[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// host-side launcher implemented per dtype in conv_bf16.hip / conv_f32.hip
+int launch_conv_bf16(const ConvArgs& a, int mode, hipStream_t s);
+int launch_conv_f32(const ConvArgs& a, int mode, hipStream_t s);
+
+
+
+}  // namespace wdm

@@ -1,0 +1,489 @@
+// HBM-bound kernels of the sampling path: Haar wavelet-packet DWT/IDWT, patch gather into the UNet input,
+// scatter-mean + DDIM update, layout conversion, GroupNorm statistics, attention softmax, the timestep-embedding
+// MLP, and weight packing.  All deterministic (no atomics): every reduction has a fixed order.
+#include "common.h"
+
+namespace wdm {
+
+static inline int nblocks(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+// =================================================================================================
+// Haar wavelet packet, 2 levels (models/wavelet.py:37-49).
+// The 16 analysis filters are f_j[p][q] = 0.25 * (-1)^(j0*(q>>1) + j1*(p>>1) + j2*(q&1) + j3*(p&1)), i.e. a 16-point
+// Walsh-Hadamard transform of the 4x4 block re-indexed as idx = (p&1)<<3 | (q&1)<<2 | (p>>1)<<1 | (q>>1): four
+// add/sub lifting stages and one scale.  Output channel = j*3 + c (sub-band major), integer-exact bookkeeping.
+// One thread per 4x4 block: 4 coalesced 16-byte reads, 16 coalesced 4-byte writes (one per sub-band plane).
+// =================================================================================================
+__device__ __forceinline__ void wht16(float* v) {
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((i & s) == 0) {
+                const float a = v[i], b = v[i | s];
+                v[i] = a + b;
+                v[i | s] = a - b;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] *= 0.25f;
+}
+
+__global__ __launch_bounds__(256) void dwt_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W) {
+    const int h = H >> 2, w = W >> 2;
+    const long long total = (long long)B * 3 * h * w;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(id % w);
+        const int u = (int)((id / w) % h);
+        const int c = (int)((id / ((long long)w * h)) % 3);
+        const int b = (int)(id / ((long long)w * h * 3));
+        const float* src = x + (((long long)b * 3 + c) * H + 4 * u) * W + 4 * v;
+        float t[16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 r = *(const float4*)(src + (long long)p * W);
+            const float rq[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[((p & 1) << 3) | ((q & 1) << 2) | ((p >> 1) << 1) | (q >> 1)] = rq[q];
+        }
+        wht16(t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) y[(((long long)b * 48 + j * 3 + c) * h + u) * w + v] = t[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void dwt_inv_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int h, int w) {
+    const int H = h << 2, W = w << 2;
+    const long long total = (long long)B * 3 * h * w;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(id % w);
+        const int u = (int)((id / w) % h);
+        const int c = (int)((id / ((long long)w * h)) % 3);
+        const int b = (int)(id / ((long long)w * h * 3));
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = y[(((long long)b * 48 + j * 3 + c) * h + u) * w + v];
+        wht16(t);   // the basis is orthonormal and symmetric in (j, idx): the inverse is the same butterfly
+        float* dst = x + (((long long)b * 3 + c) * H + 4 * u) * W + 4 * v;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float rq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rq[q] = t[((p & 1) << 3) | ((q & 1) << 2) | ((p >> 1) << 1) | (q >> 1)];
+            *(float4*)(dst + (long long)p * W) = make_float4(rq[0], rq[1], rq[2], rq[3]);
+        }
+    }
+}
+
+int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3)) WDM_FAIL(WDM_EINVAL, "dwt_fwd: H=%d W=%d must be positive multiples of 4", H, W);
+    const long long total = (long long)B * 3 * (H / 4) * (W / 4);
+    hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, x, y, B, H, W);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s) {
+    if (B <= 0 || h <= 0 || w <= 0) WDM_FAIL(WDM_EINVAL, "dwt_inv: bad shape");
+    const long long total = (long long)B * 3 * h * w;
+    hipLaunchKernelGGL(dwt_inv_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, y, x, B, h, w);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// patch gather: crop()+cat of ddm_wavelet.py:467-478, written straight into the NHWC UNet input
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pack_channels_kernel(const float* __restrict__ src, int nch, int H, int W, const int32_t* __restrict__ patches,
+                                                            int n, int p, T* __restrict__ x96, int c_total, int c_off) {
+    const long long total = (long long)n * p * p * nch;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id % nch);
+        const int xx = (int)((id / nch) % p);
+        const int yy = (int)((id / ((long long)nch * p)) % p);
+        const int k = (int)(id / ((long long)nch * p * p));
+        int img = k, hi = 0, wi = 0;
+        if (patches != nullptr) { img = patches[3 * k]; hi = patches[3 * k + 1]; wi = patches[3 * k + 2]; }
+        const float v = src[(((long long)img * nch + c) * H + hi + yy) * W + wi + xx];
+        TI<T>::st(x96, (((long long)k * p + yy) * p + xx) * c_total + c_off + c, v);
+    }
+}
+
+int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96, int c_total, int c_off, int dtype,
+                    hipStream_t s) {
+    if (n <= 0 || p <= 0 || nch <= 0 || c_off < 0 || c_off + nch > c_total) WDM_FAIL(WDM_EINVAL, "pack_channels: bad arguments");
+    if (patches == nullptr && (p != H || p != W)) WDM_FAIL(WDM_EINVAL, "pack_channels: identity patch list needs p == H == W");
+    const long long total = (long long)n * p * p * nch;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_channels_kernel<__bf16>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (__bf16*)x96, c_total, c_off);
+    else hipLaunchKernelGGL(pack_channels_kernel<float>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (float*)x96, c_total, c_off);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// scatter-mean + DDIM update (ddm_wavelet.py:485-502).  Gather form: every full-image element sums the patches that
+// cover it in patch-list order -- the same order as the reference's sequential "+=", so the fp32 sum is identical.
+// =================================================================================================
+__global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ eps, const int32_t* __restrict__ patches, int n, int p,
+                                                          const float* __restrict__ x_t, int nimg, int H, int W, float s1m, float sa, float san, float c2,
+                                                          float* __restrict__ x0o, float* __restrict__ xno) {
+    const long long total = (long long)nimg * 3 * H * W;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(id % W);
+        const int yy = (int)((id / W) % H);
+        const int c = (int)((id / ((long long)W * H)) % 3);
+        const int img = (int)(id / ((long long)W * H * 3));
+        float acc = 0.f, cnt = 0.f;
+        if (patches == nullptr) {
+            acc = eps[id];
+            cnt = 1.f;
+        } else {
+            for (int k = 0; k < n; ++k) {
+                const int pi = patches[3 * k], hi = patches[3 * k + 1], wi = patches[3 * k + 2];
+                if (pi == img && (unsigned)(yy - hi) < (unsigned)p && (unsigned)(xx - wi) < (unsigned)p) {
+                    acc += eps[(((long long)k * 3 + c) * p + (yy - hi)) * p + (xx - wi)];
+                    cnt += 1.f;
+                }
+            }
+        }
+        const float et = acc / cnt;
+        const float xt = x_t[id];
+        const float x0 = (xt - et * s1m) / sa;
+        x0o[id] = x0;
+        xno[id] = san * x0 + c2 * et;
+    }
+}
+
+int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W, float s1m, float sa, float san,
+                  float c2, float* x0, float* xn, hipStream_t s) {
+    if (n <= 0 || nimg <= 0) WDM_FAIL(WDM_EINVAL, "ddim_update: bad arguments");
+    if (patches == nullptr && (p != H || p != W || n != nimg)) WDM_FAIL(WDM_EINVAL, "ddim_update: identity patch list needs n == nimg, p == H == W");
+    const long long total = (long long)nimg * 3 * H * W;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(g), dim3(256), 0, s, eps, patches, n, p, x_t, nimg, H, W, s1m, sa, san, c2, x0, xn);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// layout conversion at the drop-in model(x, t) boundary
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id % C);
+        const long long bp = id / C;               // b*HW + pix
+        const long long b = bp / HW, pix = bp % HW;
+        TI<T>::st(dst, id, src[(b * C + c) * HW + pix]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const long long pix = id % HW;
+        const int c = (int)((id / HW) % C);
+        const long long b = id / ((long long)HW * C);
+        dst[id] = TI<T>::ld(src, (b * HW + pix) * C + c);
+    }
+}
+int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype, hipStream_t s) {
+    const long long total = (long long)B * C * H * W;
+    if (total <= 0) WDM_FAIL(WDM_EINVAL, "nchw_to_nhwc: empty tensor");
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(g), dim3(256), 0, s, src, (__bf16*)dst, B, C, H * W);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, B, C, H * W);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype, hipStream_t s) {
+    const long long total = (long long)B * C * H * W;
+    if (total <= 0) WDM_FAIL(WDM_EINVAL, "nhwc_to_nchw: empty tensor");
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)src, dst, B, C, H * W);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, dst, B, C, H * W);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// GroupNorm(32 groups, eps, biased variance) statistics -> per-(image, channel) scale / shift   (unet.py:36-37)
+//
+// Pass 1 (gn_partial_kernel): one workgroup per (pixel slab, image) streams the NHWC tensor with 16-byte loads;
+// each thread owns a fixed 16-byte channel vector and accumulates sum(x-K) and sum((x-K)^2) with the per-channel
+// pivot K = x[b, pixel 0, c] (shifted-data variance: no catastrophic cancellation), rows are reduced through LDS in
+// fixed order.  Pass 2 (gn_finalize_kernel): one wave per (image, group) re-centres the per-channel partials on a
+// common pivot and reduces them in fp64 with a fixed shuffle tree, then writes
+//     scale[b,c] = rstd*gamma[c],  shift[b,c] = beta[c] - mean*scale[b,c]
+// which the consuming conv applies while staging its A operand.  Two input tensors = the channel concat [x0 | x1];
+// groups may straddle the seam (1280 = 768 + 512 channels -> 40-channel groups).
+// =================================================================================================
+static inline int gn_nslab(int HW) { int n = HW / 64; return n < 1 ? 1 : (n > 64 ? 64 : n); }
+size_t gn_partial_bytes(int B, int HW, int C) { return (size_t)B * gn_nslab(HW) * C * 2 * sizeof(float); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int xs, int C, int HW, int nslab, int c_off, int c_total,
+                                                         float* __restrict__ partial) {
+    constexpr int VEC = TI<T>::VEC;
+    __shared__ float red[256 * VEC * 2];
+    const int cols = C / VEC;                         // 16-byte channel vectors per pixel
+    const int cb = blockIdx.z;                        // column block (cols may exceed 256 in f32 mode)
+    const int cols_here = min(cols - cb * 256, 256);
+    const int rows = 256 / cols_here;
+    const int tid = threadIdx.x;
+    const int col = tid % cols_here, row = tid / cols_here;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int pps = HW / nslab;
+    const int p0 = slab * pps, p1 = (slab == nslab - 1) ? HW : p0 + pps;
+    const int c = (cb * 256 + col) * VEC;
+    float s1[VEC], s2[VEC], piv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (row < rows) {
+        const T* base = x + (long long)b * HW * xs + c;
+        { uint4 u = *(const uint4*)base; TI<T>::unpack(u, piv); }
+        for (int p = p0 + row; p < p1; p += rows) {
+            const uint4 u = *(const uint4*)(base + (long long)p * xs);
+            float f[VEC];
+            TI<T>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = f[e] - piv[e]; s1[e] += d; s2[e] += d * d; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[(tid * VEC + e) * 2] = s1[e]; red[(tid * VEC + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    if (row == 0) {
+        for (int r = 1; r < rows; ++r) {
+            const int o = (r * cols_here + col) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s1[e] += red[(o + e) * 2]; s2[e] += red[(o + e) * 2 + 1]; }
+        }
+        float* dst = partial + (((long long)b * nslab + slab) * c_total + c_off + c) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
+                                                         int nslab, const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int gw = C / 32;
+    const int lane = threadIdx.x;
+    auto pivot = [&](int c) -> float {
+        return (c < C0) ? TI<T>::ld(x0, (long long)b * HW * xs0 + c) : TI<T>::ld(x1, (long long)b * HW * xs1 + (c - C0));
+    };
+    const double kg = (double)pivot(g * gw);
+    double S1 = 0.0, S2 = 0.0;
+    const int items = gw * nslab;
+    const double npix = (double)(HW / nslab);
+    for (int it = lane; it < items; it += 64) {
+        const int ci = it / nslab, sl = it % nslab;
+        const int c = g * gw + ci;
+        const float* pp = partial + (((long long)b * nslab + sl) * C + c) * 2;
+        const double n = (sl == nslab - 1) ? (double)(HW - (nslab - 1) * (HW / nslab)) : npix;
+        const double d = (double)pivot(c) - kg;
+        const double a1 = (double)pp[0], a2 = (double)pp[1];
+        S1 += a1 + n * d;
+        S2 += a2 + 2.0 * d * a1 + n * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        S1 += __shfl_xor(S1, o);
+        S2 += __shfl_xor(S2, o);
+    }
+    const double N = (double)gw * (double)HW;
+    const double m = S1 / N;
+    double var = S2 / N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)(kg + m);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int ci = lane; ci < gw; ci += 64) {
+        const int c = g * gw + ci;
+        const float sc = rstd * gamma[c];
+        scale[(long long)b * C + c] = sc;
+        shift[(long long)b * C + c] = beta[c] - mean * sc;
+    }
+}
+
+template <typename T>
+static int gn_launch(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale, float* shift, hipStream_t s) {
+    constexpr int VEC = TI<T>::VEC;
+    const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1;
+    const int HW = x0.H * x0.W;
+    if (C != nw.c || C % 32) WDM_FAIL(WDM_EINVAL, "groupnorm: %d channels vs %d weights (must be a multiple of 32)", C, nw.c);
+    if (C0 % VEC || C1 % VEC) WDM_FAIL(WDM_EINVAL, "groupnorm: channel counts must be multiples of %d", VEC);
+    const int nslab = gn_nslab(HW);
+    {
+        const int cols = C0 / VEC;
+        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0.p, x0.xs, C0, HW, nslab, 0, C, partial);
+    }
+    if (C1) {
+        const int cols = C1 / VEC;
+        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x1->p, x1->xs, C1, HW, nslab, C0, C, partial);
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(32, B), dim3(64), 0, s, (const T*)x0.p, x0.xs, C0, x1 ? (const T*)x1->p : (const T*)x0.p, x1 ? x1->xs : 0, C,
+                       HW, nslab, partial, nw.g, nw.b, eps, scale, shift);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale, float* shift, int dtype,
+                     hipStream_t s) {
+    return dtype == WDM_BF16 ? gn_launch<__bf16>(x0, x1, B, nw, eps, partial, scale, shift, s) : gn_launch<float>(x0, x1, B, nw, eps, partial, scale, shift, s);
+}
+
+// GroupNorm apply without activation (AttnBlock.norm, unet.py:169-170): y = x*scale + shift, NHWC dense output
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int xs, int C, int HW, long long nvec, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, T* __restrict__ y) {
+    constexpr int VEC = TI<T>::VEC;
+    const int cols = C / VEC;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec; id += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(id % cols);
+        const long long bp = id / cols;
+        const long long b = bp / HW;
+        const int c = col * VEC;
+        const uint4 u = *(const uint4*)(x + bp * xs + c);
+        float f[VEC];
+        TI<T>::unpack(u, f);
+        const float* ps = scale + b * C + c;
+        const float* pf = shift + b * C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = f[e] * ps[e] + pf[e];
+        *(uint4*)(y + bp * C + c) = TI<T>::pack(f);
+    }
+}
+int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s) {
+    const int HW = x.H * x.W;
+    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const long long nvec = (long long)B * HW * (x.C / vec);
+    const int g = nblocks(nvec, 256) > 16384 ? 16384 : nblocks(nvec, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nvec, scale, shift, (__bf16*)y);
+    else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nvec, scale, shift, (float*)y);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// attention softmax over keys (unet.py:179): one wave per query row, wavefront-shuffle max / sum reductions
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, T* __restrict__ P, long long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = S + row * n;
+    float v[8];
+    const int per = n / 64;    // n in {64, 128, 256, 512}
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < per) { v[i] = src[lane + i * 64]; mx = fmaxf(mx, v[i]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < per) { v[i] = expf(v[i] - mx); sum += v[i]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < per) TI<T>::st(P, row * n + lane + i * 64, v[i] * inv);
+}
+int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s) {
+    if (n % 64 || n > 512 || n <= 0) WDM_FAIL(WDM_EINVAL, "softmax: row length %d must be a multiple of 64 and <= 512", n);
+    const int g = (int)((rows + 3) / 4);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(softmax_rows_kernel<__bf16>, dim3(g), dim3(256), 0, s, S, (__bf16*)P, rows, n);
+    else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(g), dim3(256), 0, s, S, (float*)P, rows, n);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// timestep embedding + Linear layers of the temb path (unet.py:10-28, 354-357, 125), all fp32
+// =================================================================================================
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int n_t, int dim, float* __restrict__ emb) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (id >= n_t * half) return;
+    const int n = id / half, i = id % half;
+    const float w = expf((float)i * -(logf(10000.0f) / (float)(half - 1)));
+    const float a = t[n] * w;
+    emb[n * dim + i] = sinf(a);
+    emb[n * dim + half + i] = cosf(a);
+}
+int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream_t s) {
+    if (dim % 2 || dim < 4) WDM_FAIL(WDM_EINVAL, "timestep embedding: dim %d must be even", dim);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(nblocks((long long)n_t * dim / 2, 64)), dim3(64), 0, s, t, n_t, dim, emb);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, int n, int k, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     int o, float* __restrict__ out, int act) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)n * o) return;
+    const int row = (int)(wid / o), oc = (int)(wid % o);
+    const float* x = in + (long long)row * k;
+    const float* w = W + (long long)oc * k;
+    float acc = 0.f;
+    for (int i = lane; i < k; i += 64) {
+        float v = x[i];
+        if (act == 1) v = v / (1.0f + expf(-v));
+        acc += v * w[i];
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) {
+        float r = acc + (bias ? bias[oc] : 0.f);
+        if (act == 2) r = r / (1.0f + expf(-r));
+        out[(long long)row * o + oc] = r;
+    }
+}
+int k_linear(const float* in, int n, int k, const float* W, const float* b, int o, float* out, int act, hipStream_t s) {
+    const long long waves = (long long)n * o;
+    hipLaunchKernelGGL(linear_kernel, dim3((int)((waves + 3) / 4)), dim3(256), 0, s, in, n, k, W, b, o, out, act);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// weight packing: OIHW f32 -> [tap][rows_total][cin] in the model dtype
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int cout, int cin, int kk, T* __restrict__ dst, int rows_total, int row_off,
+                                                        int rows_span) {
+    // rows [row_off, row_off + cout) get the weights, rows [row_off + cout, row_off + rows_span) are zero padding
+    const long long total = (long long)rows_span * cin * kk;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(id % cin);
+        const int o = (int)((id / cin) % rows_span);
+        const int tap = (int)(id / ((long long)cin * rows_span));
+        const float v = (o < cout) ? w[((long long)o * cin + ci) * kk + tap] : 0.f;
+        TI<T>::st(dst, ((long long)tap * rows_total + row_off + o) * cin + ci, v);
+    }
+}
+int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail, int dtype, hipStream_t s) {
+    const int rows_span = zero_tail ? rows_total - row_off : cout;
+    const long long total = (long long)rows_span * cin * k * k;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, k * k, (__bf16*)dst, rows_total, row_off, rows_span);
+    else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, k * k, (float*)dst, rows_total, row_off, rows_span);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s) {
+    WDM_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return WDM_OK;
+}
+
+}  // namespace wdm

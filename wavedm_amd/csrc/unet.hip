@@ -1,0 +1,397 @@
+// Whole-UNet executor: builds the layer list of the reference's DiffusionUNet (models/unet.py:197-307) from the
+// config, owns the layout of the single packed-weight buffer, and runs forward (unet.py:346-395) as a fixed sequence
+// of fused-kernel launches on one stream.  Parameter names / shapes are exactly the reference's state_dict keys.
+#include <string.h>
+
+#include <map>
+#include <string>
+
+#include "common.h"
+
+namespace wdm {
+const char* get_error();
+}
+using namespace wdm;
+
+namespace {
+
+enum ParamKind { PK_CONV, PK_F32 };
+
+struct ParamSlot {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    ParamKind kind = PK_F32;
+    size_t off = 0;       // byte offset of the destination matrix / vector in the packed buffer
+    int rows_total = 0;   // PK_CONV: rows of the destination matrix (fused qk: 2C)
+    int row_off = 0;      // PK_CONV: first destination row;  PK_F32: element offset inside the destination vector
+    bool zero_tail = true;   // PK_CONV: this slot also zero-fills the padding rows behind it
+    bool loaded = false;
+    int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+
+struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; };
+struct NormD { size_t g_off, b_off; int c; };
+struct ResD { int cin, cout; NormD n1, n2; ConvD c1, c2, nin; bool has_nin; int temb_row; };
+struct AttnD { int c; NormD n; ConvD qk, v, proj; };
+
+}  // namespace
+
+struct wdm_unet {
+    wdm_handle* h;
+    wdm_unet_config cfg;
+    std::vector<ParamSlot> params;
+    std::map<std::string, int> index;
+    size_t packed_bytes = 0;
+    char* packed = nullptr;
+    bool all_loaded = false;
+    int temb_ch = 0, temb_rows = 0;   // rows of the concatenated temb_proj matrix
+    size_t temb_w_off = 0, temb_b_off = 0, d0w = 0, d0b = 0, d1w = 0, d1b = 0;
+    ConvD conv_in, conv_out;
+    NormD norm_out;
+    std::vector<std::vector<ResD>> down_res, up_res;
+    std::vector<std::vector<AttnD>> down_attn, up_attn;
+    std::vector<ConvD> down_ds, up_us;   // per level (unused entries have cin == 0)
+    ResD mid1, mid2;
+    AttnD mid_attn;
+
+    // ---- construction helpers
+    size_t take(size_t bytes) { size_t o = packed_bytes; packed_bytes = align_up(packed_bytes + bytes, 256); return o; }
+    void add_param(const std::string& name, std::initializer_list<int64_t> shp, ParamKind kind, size_t off, int rows_total, int row_off) {
+        ParamSlot p;
+        p.name = name; p.kind = kind; p.off = off; p.rows_total = rows_total; p.row_off = row_off;
+        p.ndim = (int)shp.size();
+        int i = 0;
+        for (auto v : shp) p.shape[i++] = v;
+        index[name] = (int)params.size();
+        params.push_back(p);
+    }
+    ConvD add_conv(const std::string& name, int cin, int cout, int k) {
+        ConvD d{};
+        d.cin = cin; d.cout = cout; d.k = k; d.rows_pad = conv_rows_pad(cout);
+        d.w_off = take(conv_packed_bytes(cin, cout, k, cfg.dtype));
+        d.b_off = take((size_t)cout * 4);
+        add_param(name + ".weight", {cout, cin, k, k}, PK_CONV, d.w_off, d.rows_pad, 0);
+        add_param(name + ".bias", {cout}, PK_F32, d.b_off, 0, 0);
+        return d;
+    }
+    NormD add_norm(const std::string& name, int c) {
+        NormD d{};
+        d.c = c;
+        d.g_off = take((size_t)c * 4);
+        d.b_off = take((size_t)c * 4);
+        add_param(name + ".weight", {c}, PK_F32, d.g_off, 0, 0);
+        add_param(name + ".bias", {c}, PK_F32, d.b_off, 0, 0);
+        return d;
+    }
+    ResD add_res(const std::string& name, int cin, int cout, std::vector<std::pair<std::string, int>>& temb_list) {
+        ResD r{};
+        r.cin = cin; r.cout = cout;
+        r.n1 = add_norm(name + ".norm1", cin);
+        r.c1 = add_conv(name + ".conv1", cin, cout, 3);
+        r.temb_row = temb_rows;
+        temb_list.push_back({name + ".temb_proj", cout});
+        temb_rows += cout;
+        r.n2 = add_norm(name + ".norm2", cout);
+        r.c2 = add_conv(name + ".conv2", cout, cout, 3);
+        r.has_nin = cin != cout;
+        if (r.has_nin) r.nin = add_conv(name + ".nin_shortcut", cin, cout, 1);
+        return r;
+    }
+    AttnD add_attn(const std::string& name, int c) {
+        AttnD a{};
+        a.c = c;
+        a.n = add_norm(name + ".norm", c);
+        // q and k are fused into one [2C][C] matrix: one pass over the normalised input produces both
+        ConvD qk{};
+        qk.cin = c; qk.cout = 2 * c; qk.k = 1; qk.rows_pad = conv_rows_pad(2 * c);
+        qk.w_off = take(conv_packed_bytes(c, 2 * c, 1, cfg.dtype));
+        qk.b_off = take((size_t)2 * c * 4);
+        add_param(name + ".q.weight", {c, c, 1, 1}, PK_CONV, qk.w_off, qk.rows_pad, 0);
+        params.back().zero_tail = false;   // the k slot below owns the rows behind q
+        add_param(name + ".q.bias", {c}, PK_F32, qk.b_off, 0, 0);
+        add_param(name + ".k.weight", {c, c, 1, 1}, PK_CONV, qk.w_off, qk.rows_pad, c);
+        add_param(name + ".k.bias", {c}, PK_F32, qk.b_off, 0, c);
+        a.qk = qk;
+        a.v = add_conv(name + ".v", c, c, 1);
+        a.proj = add_conv(name + ".proj_out", c, c, 1);
+        return a;
+    }
+
+    int build();
+    ConvW cw(const ConvD& d) const { ConvW w; w.w = packed + d.w_off; w.b = (const float*)(packed + d.b_off); w.cin = d.cin; w.cout = d.cout; w.k = d.k; w.rows_pad = d.rows_pad; return w; }
+    NormW nw(const NormD& d) const { NormW n; n.g = (const float*)(packed + d.g_off); n.b = (const float*)(packed + d.b_off); n.c = d.c; return n; }
+    ResW rw(const ResD& d, const float* temb_all, int n_t) const {
+        ResW r;
+        r.cin = d.cin; r.cout = d.cout; r.n1 = nw(d.n1); r.n2 = nw(d.n2); r.c1 = cw(d.c1); r.c2 = cw(d.c2);
+        r.has_nin = d.has_nin;
+        if (d.has_nin) r.nin = cw(d.nin);
+        r.temb = temb_all ? temb_all + d.temb_row : nullptr;
+        r.temb_ld = temb_rows;
+        r.temb_per_image = n_t > 1;
+        return r;
+    }
+    AttnW aw(const AttnD& d) const { AttnW a; a.c = d.c; a.n = nw(d.n); a.qk = cw(d.qk); a.v = cw(d.v); a.proj = cw(d.proj); return a; }
+
+    int forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out);
+};
+
+int wdm_unet::build() {
+    const int ch = cfg.ch, nres = cfg.n_levels, nrb = cfg.num_res_blocks;
+    temb_ch = ch * 4;
+    auto is_attn = [&](int res) { for (int i = 0; i < cfg.n_attn_res; ++i) if (cfg.attn_resolutions[i] == res) return true; return false; };
+    std::vector<std::pair<std::string, int>> temb_list;
+
+    d0w = take((size_t)temb_ch * ch * 4); d0b = take((size_t)temb_ch * 4);
+    add_param("temb.dense.0.weight", {temb_ch, ch}, PK_F32, d0w, 0, 0);
+    add_param("temb.dense.0.bias", {temb_ch}, PK_F32, d0b, 0, 0);
+    d1w = take((size_t)temb_ch * temb_ch * 4); d1b = take((size_t)temb_ch * 4);
+    add_param("temb.dense.1.weight", {temb_ch, temb_ch}, PK_F32, d1w, 0, 0);
+    add_param("temb.dense.1.bias", {temb_ch}, PK_F32, d1b, 0, 0);
+    conv_in = add_conv("conv_in", cfg.in_channels, ch, 3);
+
+    int res = cfg.resolution;
+    int block_in = ch;
+    down_res.resize(nres); down_attn.resize(nres); down_ds.assign(nres, ConvD{});
+    up_res.resize(nres); up_attn.resize(nres); up_us.assign(nres, ConvD{});
+    for (int l = 0; l < nres; ++l) {
+        block_in = ch * (l == 0 ? 1 : cfg.ch_mult[l - 1]);
+        const int block_out = ch * cfg.ch_mult[l];
+        for (int b = 0; b < nrb; ++b) {
+            down_res[l].push_back(add_res("down." + std::to_string(l) + ".block." + std::to_string(b), block_in, block_out, temb_list));
+            block_in = block_out;
+        }
+        if (is_attn(res))
+            for (int b = 0; b < nrb; ++b) down_attn[l].push_back(add_attn("down." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
+        if (l != nres - 1) {
+            down_ds[l] = add_conv("down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3);
+            res /= 2;
+        }
+    }
+    mid1 = add_res("mid.block_1", block_in, block_in, temb_list);
+    mid_attn = add_attn("mid.attn_1", block_in);
+    mid2 = add_res("mid.block_2", block_in, block_in, temb_list);
+    for (int l = nres - 1; l >= 0; --l) {
+        const int block_out = ch * cfg.ch_mult[l];
+        int skip_in = ch * cfg.ch_mult[l];
+        for (int b = 0; b <= nrb; ++b) {
+            if (b == nrb) skip_in = ch * (l == 0 ? 1 : cfg.ch_mult[l - 1]);
+            up_res[l].push_back(add_res("up." + std::to_string(l) + ".block." + std::to_string(b), block_in + skip_in, block_out, temb_list));
+            block_in = block_out;
+        }
+        if (is_attn(res))
+            for (int b = 0; b <= nrb; ++b) up_attn[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
+        if (l != 0) {
+            up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3);
+            res *= 2;
+        }
+    }
+    norm_out = add_norm("norm_out", block_in);
+    conv_out = add_conv("conv_out", block_in, cfg.out_ch, 3);
+
+    // all temb_proj Linear layers concatenated into one [sum(cout)][temb_ch] fp32 matrix: one GEMV launch per step
+    temb_w_off = take((size_t)temb_rows * temb_ch * 4);
+    temb_b_off = take((size_t)temb_rows * 4);
+    int row = 0;
+    for (auto& e : temb_list) {
+        add_param(e.first + ".weight", {e.second, temb_ch}, PK_F32, temb_w_off, 0, row * temb_ch);
+        add_param(e.first + ".bias", {e.second}, PK_F32, temb_b_off, 0, row);
+        row += e.second;
+    }
+    return WDM_OK;
+}
+
+int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out) {
+    const int nres = cfg.n_levels, nrb = cfg.num_res_blocks, R = cfg.resolution;
+    // ---- timestep embedding MLP + every block's temb projection (depends only on t)
+    float *emb, *t0, *t1, *temb_all;
+    auto af = [&](size_t n, float** p) -> int { *p = (float*)c.ar->alloc(n * 4); if (!*p) WDM_FAIL(WDM_ENOMEM, "workspace too small"); return WDM_OK; };
+    WDM_TRY(af((size_t)n_t * cfg.ch, &emb));
+    WDM_TRY(af((size_t)n_t * temb_ch, &t0));
+    WDM_TRY(af((size_t)n_t * temb_ch, &t1));
+    WDM_TRY(af((size_t)n_t * temb_rows, &temb_all));
+    if (!c.dry) {
+        WDM_TRY(k_timestep_embedding(t, n_t, cfg.ch, emb, c.s));
+        WDM_TRY(k_linear(emb, n_t, cfg.ch, (const float*)(packed + d0w), (const float*)(packed + d0b), temb_ch, t0, 2, c.s));
+        WDM_TRY(k_linear(t0, n_t, temb_ch, (const float*)(packed + d1w), (const float*)(packed + d1b), temb_ch, t1, 0, c.s));
+        WDM_TRY(k_linear(t1, n_t, temb_ch, (const float*)(packed + temb_w_off), (const float*)(packed + temb_b_off), temb_rows, temb_all, 1, c.s));
+    }
+    c.ar->free(emb); c.ar->free(t0); c.ar->free(t1);
+
+    Tens x;
+    x.p = (void*)x96; x.C = cfg.in_channels; x.H = R; x.W = R; x.xs = cfg.in_channels;
+    std::vector<Tens> hs;
+    Tens h;
+    WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr));
+    hs.push_back(h);
+    for (int l = 0; l < nres; ++l) {
+        for (int b = 0; b < nrb; ++b) {
+            Tens o;
+            WDM_TRY(run_resblock(c, rw(down_res[l][b], temb_all, n_t), hs.back(), nullptr, &o));
+            if (!down_attn[l].empty()) {
+                Tens o2;
+                WDM_TRY(run_attn(c, aw(down_attn[l][b]), o, &o2));
+                free_tens(c, o);
+                o = o2;
+            }
+            hs.push_back(o);
+        }
+        if (l != nres - 1) {
+            Tens o;
+            WDM_TRY(run_conv(c, cw(down_ds[l]), MODE_S2, hs.back(), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr));
+            hs.push_back(o);
+        }
+    }
+    // ---- middle (input stays on the skip stack)
+    Tens m1, m2;
+    WDM_TRY(run_resblock(c, rw(mid1, temb_all, n_t), hs.back(), nullptr, &m1));
+    WDM_TRY(run_attn(c, aw(mid_attn), m1, &m2));
+    free_tens(c, m1);
+    WDM_TRY(run_resblock(c, rw(mid2, temb_all, n_t), m2, nullptr, &h));
+    free_tens(c, m2);
+    // ---- up path: ResnetBlock on cat([h, skip]) without materialising the concat
+    for (int l = nres - 1; l >= 0; --l) {
+        for (int b = 0; b <= nrb; ++b) {
+            Tens skip = hs.back();
+            hs.pop_back();
+            Tens o;
+            WDM_TRY(run_resblock(c, rw(up_res[l][b], temb_all, n_t), h, &skip, &o));
+            free_tens(c, h);
+            free_tens(c, skip);
+            h = o;
+            if (!up_attn[l].empty()) {
+                Tens o2;
+                WDM_TRY(run_attn(c, aw(up_attn[l][b]), h, &o2));
+                free_tens(c, h);
+                h = o2;
+            }
+        }
+        if (l != 0) {
+            Tens o;
+            WDM_TRY(run_conv(c, cw(up_us[l]), MODE_UPS, h, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr));
+            free_tens(c, h);
+            h = o;
+        }
+    }
+    // ---- norm_out -> SiLU -> conv_out, written as NCHW fp32 (the reference's output layout)
+    {
+        float *sc, *sh, *partial;
+        WDM_TRY(af((size_t)c.B * h.C, &sc));
+        WDM_TRY(af((size_t)c.B * h.C, &sh));
+        WDM_TRY(af(gn_partial_bytes(c.B, h.H * h.W, h.C) / 4, &partial));
+        if (!c.dry) WDM_TRY(k_gn_scale_shift(h, nullptr, c.B, nw(norm_out), 1e-6f, partial, sc, sh, c.dtype, c.s));
+        c.ar->free(partial);
+        Tens dummy;
+        WDM_TRY(run_conv(c, cw(conv_out), MODE_S1, h, nullptr, sc, sh, nullptr, 0, 0, nullptr, &dummy, Y_NCHW_F32, eps_out));
+        c.ar->free(sc); c.ar->free(sh);
+    }
+    free_tens(c, h);
+    c.ar->free(temb_all);
+    if (!hs.empty()) WDM_FAIL(WDM_ESTATE, "internal: skip stack not empty (%zu)", hs.size());
+    return WDM_OK;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int wdm_abi_version(void) { return WDM_ABI_VERSION; }
+const char* wdm_last_error(void) { return wdm::get_error(); }
+
+int wdm_create(int device, wdm_handle** out) {
+    if (!out) WDM_FAIL(WDM_EINVAL, "wdm_create: null out");
+    int n = 0;
+    WDM_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) WDM_FAIL(WDM_EINVAL, "wdm_create: device %d of %d", device, n);
+    hipDeviceProp_t prop;
+    WDM_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) WDM_FAIL(WDM_EINVAL, "wdm_create: device is %s, this library is built for gfx950 only", prop.gcnArchName);
+    *out = new wdm_handle{device};
+    return WDM_OK;
+}
+int wdm_destroy(wdm_handle* h) { delete h; return WDM_OK; }
+
+int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out) {
+    if (!cfg || !out) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: null argument");   // h may be NULL for host-only layout queries
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad level count");
+    if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
+    if (!cfg->resamp_with_conv) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resamp_with_conv=False is not supported");
+    if (cfg->ch % 32 || cfg->in_channels % 32) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: ch and in_channels must be multiples of 32");
+    if (cfg->resolution % (8 << (cfg->n_levels - 1))) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resolution %d too small for %d levels (coarsest level must be a multiple of 8)", cfg->resolution, cfg->n_levels);
+    if (cfg->out_ch > 16) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: out_ch > 16 unsupported");
+    wdm_unet* u = new wdm_unet();
+    u->h = h;
+    u->cfg = *cfg;
+    int rc = u->build();
+    if (rc != WDM_OK) { delete u; return rc; }
+    *out = u;
+    return WDM_OK;
+}
+int wdm_unet_destroy(wdm_unet* u) { delete u; return WDM_OK; }
+int wdm_unet_num_params(const wdm_unet* u) { return u ? (int)u->params.size() : 0; }
+int wdm_unet_param_info(const wdm_unet* u, int i, const char** name, int* ndim, int64_t shape[4]) {
+    if (!u || i < 0 || i >= (int)u->params.size()) WDM_FAIL(WDM_EINVAL, "wdm_unet_param_info: index %d out of range", i);
+    const ParamSlot& p = u->params[i];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = p.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    return WDM_OK;
+}
+size_t wdm_unet_packed_bytes(const wdm_unet* u) { return u ? u->packed_bytes : 0; }
+int wdm_unet_set_packed(wdm_unet* u, void* packed, size_t bytes) {
+    if (!u || !packed) WDM_FAIL(WDM_EINVAL, "wdm_unet_set_packed: null argument");
+    if (bytes < u->packed_bytes) WDM_FAIL(WDM_ENOMEM, "wdm_unet_set_packed: %zu bytes given, %zu needed", bytes, u->packed_bytes);
+    if (((uintptr_t)packed) & 255) WDM_FAIL(WDM_EINVAL, "wdm_unet_set_packed: buffer must be 256-byte aligned");
+    u->packed = (char*)packed;
+    for (auto& p : u->params) p.loaded = false;
+    u->all_loaded = false;
+    return WDM_OK;
+}
+int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int64_t numel, void* stream) {
+    if (!u || !name || !dev_src) WDM_FAIL(WDM_EINVAL, "wdm_unet_load_param: null argument");
+    if (!u->packed) WDM_FAIL(WDM_ESTATE, "wdm_unet_load_param: call wdm_unet_set_packed first");
+    auto it = u->index.find(name);
+    if (it == u->index.end()) WDM_FAIL(WDM_ENOTFOUND, "unknown parameter '%s'", name);
+    ParamSlot& p = u->params[it->second];
+    if (numel != p.numel()) WDM_FAIL(WDM_EINVAL, "parameter '%s': %lld elements given, %lld expected", name, (long long)numel, (long long)p.numel());
+    hipStream_t s = (hipStream_t)stream;
+    if (p.kind == PK_CONV) {
+        const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
+        WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s));
+    } else {
+        WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
+    }
+    p.loaded = true;
+    bool all = true;
+    for (auto& q : u->params) all = all && q.loaded;
+    u->all_loaded = all;
+    return WDM_OK;
+}
+int wdm_unet_mark_loaded(wdm_unet* u) {
+    if (!u || !u->packed) WDM_FAIL(WDM_ESTATE, "wdm_unet_mark_loaded: no packed buffer");
+    for (auto& p : u->params) p.loaded = true;
+    u->all_loaded = true;
+    return WDM_OK;
+}
+size_t wdm_unet_workspace_bytes(const wdm_unet* u, int B) {
+    if (!u || B <= 0) return 0;
+    Arena ar = Arena::dry();
+    Ctx c{nullptr, u->cfg.dtype, B, &ar, true};
+    int rc = const_cast<wdm_unet*>(u)->forward(c, (const void*)(uintptr_t)4096, nullptr, 1, nullptr);
+    // n_t = B needs B-1 more rows of temb scratch than n_t = 1: account for the larger case
+    if (rc != WDM_OK) return 0;
+    const size_t extra = (size_t)(B - 1) * (u->cfg.ch + 2 * (size_t)u->temb_ch + u->temb_rows) * 4 + 4096;
+    return ar.peak() + align_up(extra, 256);
+}
+int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int B, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!u || !x96 || !t || !eps_out || !workspace) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward: null argument");
+    if (!u->all_loaded) WDM_FAIL(WDM_ESTATE, "wdm_unet_forward: parameters not loaded");
+    if (B <= 0 || (n_t != 1 && n_t != B)) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward: n_t=%d must be 1 or B=%d", n_t, B);
+    if (((uintptr_t)workspace) & 255) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward: workspace must be 256-byte aligned");
+    Arena ar(workspace, workspace_bytes);
+    Ctx c{(hipStream_t)stream, u->cfg.dtype, B, &ar, false};
+    return u->forward(c, x96, t, n_t, eps_out);
+}
+
+}  // extern "C"

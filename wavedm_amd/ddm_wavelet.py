@@ -1,0 +1,152 @@
+"""DenoisingDiffusion_Wavelet -- the reference's call surface (`models/ddm_wavelet.py:127-506`)
+in front of the HIP sampling path.
+
+Kept: constructor `(args, config)`, attributes `.model .wavelet_dec .wavelet_rec .generator
+.betas .num_timesteps .device`, `sample_image(...)`, `diffusive_restoration(...)`,
+`overlapping_grid_indices(...)`, `generalized_steps_overlapping(...)`, `load_ddm_ckpt(path, ema)`
+and the checkpoint dict format (`state_dict` with the reference's keys, optional `ema_helper`).
+Not rebuilt: training (`train`) and the HFRM network -- `.generator` is whatever
+callable the user passes (`generator=`); default = identity, the stand-in BASELINE.md §3 names.
+Deliberate differences: the model is NOT wrapped in DistributedDataParallel (inference needs no
+gradient all-reduce; `.model.module` is provided for callers that unwrap), outputs stay on the
+GPU (no per-step `.to('cpu')`), and the per-step statistics print is opt-in (`verbose=True`)."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import sampling
+from .unet import DiffusionUNet
+from .wavelet import WaveletTransform
+
+
+def data_transform(X):             # ddm_wavelet.py:27-28
+    return 2 * X - 1.0
+
+
+def inverse_data_transform(X):     # ddm_wavelet.py:31-32
+    return torch.clamp((X + 1.0) / 2.0, 0.0, 1.0)
+
+
+class _Unwrapped(torch.nn.Module):
+    """Gives `.module` (as DDP would) without wrapping anything."""
+
+
+class DenoisingDiffusion_Wavelet(object):
+    def __init__(self, args, config, generator=None, dtype=None, verbose=False):
+        super().__init__()
+        self.args = args
+        self.config = config
+        self.device = torch.device(config.device) if hasattr(config, "device") else torch.device("cuda", getattr(args, "local_rank", 0))
+        if self.device.type != "cuda":
+            raise RuntimeError("wavedm_amd runs on MI355X only: config.device must be a cuda (ROCm) device")
+        self.verbose = verbose
+
+        self.wavelet_dec = WaveletTransform(scale=2, dec=True)
+        self.wavelet_rec = WaveletTransform(scale=2, dec=False)
+        self.generator = generator if generator is not None else (lambda x: x)   # HFRM stand-in (out of scope)
+
+        if getattr(config.data, "global_attn", False):
+            raise NotImplementedError("data.global_attn=True (DiffusionUNet_Global) is outside the accelerated path")
+        self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
+        self.model.module = self.model          # callers written for the DDP-wrapped model keep working
+        self.start_epoch, self.step = 0, 0
+        self.ema_shadow = None
+
+        if os.path.isfile(getattr(args, "resume", "") or ""):
+            self.load_ddm_ckpt(args.resume)
+
+        betas = sampling.get_beta_schedule(
+            beta_schedule=config.diffusion.beta_schedule, beta_start=config.diffusion.beta_start,
+            beta_end=config.diffusion.beta_end, num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
+        self.betas = torch.from_numpy(betas).float().to(self.device)
+        self.num_timesteps = self.betas.shape[0]
+
+    # ---- checkpoint (utils/logging.py:21-29 + ddm_wavelet.py:180-190) -------------------------
+    def load_ddm_ckpt(self, load_path, ema=False):
+        ckpt = torch.load(load_path, map_location="cpu", weights_only=False)
+        self.start_epoch = ckpt.get("epoch", 0)
+        self.step = ckpt.get("step", 0)
+        sd = ckpt["state_dict"]
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        self.model.load_state_dict(sd, strict=True)
+        self.ema_shadow = ckpt.get("ema_helper")
+        if ema and self.ema_shadow is not None:                                # EMAHelper.ema, ddm_wavelet.py:55-60
+            with torch.no_grad():
+                for name, p in self.model.named_parameters():
+                    if name in self.ema_shadow:
+                        p.copy_(self.ema_shadow[name].to(p.device))
+        self.model.pack_weights(force=True)
+        print("=> loaded checkpoint '{}' (epoch {}, step {})".format(load_path, self.start_epoch, self.step))
+
+    def train(self, DATASET):
+        raise NotImplementedError("training is outside the accelerated sampling path (SURVEY.md §8f-3)")
+
+    # ---- sampling ----------------------------------------------------------------------------------
+    def sample_image(self, x_cond, x, x_other=None, last=True, patch_locs=None, patch_size=None, total=None,
+                     use_global=False, use_other=False):
+        """ddm_wavelet.py:295-309."""
+        skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
+        seq = range(0, self.config.diffusion.num_diffusion_timesteps, skip)
+        if patch_locs is None:
+            raise NotImplementedError("sample_image without patch_locs is the pixel-domain path (utils/sampling.py:23)")
+        xs = self.generalized_steps_overlapping(x, x_cond, seq, self.model, self.betas, eta=0., corners=patch_locs,
+                                                p_size=patch_size, total=total, use_global=use_global,
+                                                x_other=x_other, use_other=use_other)
+        if last:
+            xs = xs[0][-1]
+        return xs
+
+    def generalized_steps_overlapping(self, x, x_cond, seq, model, b, eta=0., corners=None, p_size=None,
+                                      manual_batching=True, total=None, x_other=None, use_global=False, use_other=False):
+        """ddm_wavelet.py:437-506 on the device."""
+        if eta != 0.:
+            raise NotImplementedError("only eta = 0 (DDIM) is used by the reference (ddm_wavelet.py:303)")
+        if use_global:
+            raise NotImplementedError("use_global=True is outside the accelerated path")
+        if not (use_other and x_other is not None):
+            raise NotImplementedError("use_other=False changes the UNet input width; raindrop_wavelet.yml sets it True")
+        if not self.config.data.begin_from_noise:                              # ddm_wavelet.py:445-447
+            a = (1 - b).cumprod(dim=0)[self.num_timesteps - 1]
+            x = x_cond[:, :x.shape[1]] * a.sqrt() + x * (1.0 - a).sqrt()
+        xs, x0_preds = sampling.ddim_sample(model, x, x_cond, x_other, list(seq), b, corners=corners, p_size=p_size,
+                                            max_batch=getattr(self.args, "max_batch", 64))
+        if self.verbose:
+            for i_t, x0, xn in zip(reversed(list(seq)), x0_preds, xs[1:]):
+                print(f"t:{i_t} x0 pred:{x0.mean().item()} x next:{xn.mean().item()}")
+        return xs, x0_preds
+
+    def overlapping_grid_indices(self, x_cond, output_size, r=None):
+        """ddm_wavelet.py:426-435."""
+        _, c, h, w = x_cond.shape
+        return sampling.overlapping_grid_indices(h, w, output_size, r)
+
+    def diffusive_restoration(self, x_cond, x_other=None, r=None, last=True, total=None, use_global=False, use_other=False):
+        """ddm_wavelet.py:413-424."""
+        p_size = self.config.data.patch_size if self.config.data.wavelet_in_unet else self.config.data.image_size
+        h_list, w_list = self.overlapping_grid_indices(x_cond, output_size=p_size, r=r)
+        corners = [(i, j) for i in h_list for j in w_list]
+        x = torch.randn((x_cond.shape[0], self.config.model.pred_channels, x_cond.shape[2], x_cond.shape[3]), device=self.device)
+        return self.sample_image(x_cond, x, x_other=x_other, patch_locs=corners, last=last, patch_size=p_size,
+                                 total=total, use_global=use_global, use_other=use_other)
+
+    # ---- batched independent crops (BASELINE.json configs 0-3) --------------------------------------------
+    def restore_batch(self, rainy01, x_T, hfrm_out01=None, keep=-5):
+        """B independent patch_size x patch_size crops: DWT -> S-step DDIM -> IDWT, all on the GPU.
+
+        rainy01 (B,3,4R,4R) in [0,1]; x_T (B,3,R,R) start noise; returns the restored (B,3,4R,4R) in [0,1] built
+        from x0_preds[keep] like restoration.py:108-134, plus (xs[-1], x0_preds[keep])."""
+        x_cond = self.wavelet_dec(data_transform(rainy01))
+        hf = self.generator(rainy01) if hfrm_out01 is None else hfrm_out01
+        hf_wav = self.wavelet_dec(data_transform(hf))
+        ob = self.config.model.other_channels_begin
+        x_other = hf_wav[:, ob:].contiguous()
+        skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
+        seq = list(range(0, self.config.diffusion.num_diffusion_timesteps, skip))
+        xs, x0_preds = sampling.ddim_sample(self.model, x_T, x_cond, x_other, seq, self.betas, corners=None,
+                                            max_batch=getattr(self.args, "max_batch", 64))
+        pc = self.config.model.pred_channels
+        x0 = x0_preds[keep]
+        out = torch.cat([x0[:, :pc], hf_wav[:, pc:]], dim=1)
+        return inverse_data_transform(self.wavelet_rec(out)), xs[-1], x0

@@ -1,0 +1,123 @@
+"""Device-resident DDIM sampler with overlapping-patch stitching.
+
+Mirrors `utils/sampling.py:10-13` (compute_alpha) and `models/ddm_wavelet.py:413-506`
+(overlapping_grid_indices, generalized_steps_overlapping, eta = 0): per timestep the patches are
+gathered straight into the NHWC UNet input, the UNet runs on all patches, and one kernel does the
+scatter-add in corner order, the division by the overlap count and the DDIM update.  Unlike the
+reference nothing leaves the GPU inside the loop (it does `.to('cpu')` twice and four `.item()`
+syncs per step, ddm_wavelet.py:498-504)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
+    """ddm_wavelet.py:87-105 (float64 numpy array; the caller casts to fp32 like ddm_wavelet.py:177)."""
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_diffusion_timesteps, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, num_diffusion_timesteps, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(num_diffusion_timesteps, dtype=np.float64)
+    elif beta_schedule == "jsd":
+        betas = 1.0 / np.linspace(num_diffusion_timesteps, 1, num_diffusion_timesteps, dtype=np.float64)
+    elif beta_schedule == "sigmoid":
+        x = np.linspace(-6, 6, num_diffusion_timesteps)
+        betas = 1 / (np.exp(-x) + 1) * (beta_end - beta_start) + beta_start
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (num_diffusion_timesteps,)
+    return betas
+
+
+def alpha_bar_table(betas: torch.Tensor) -> torch.Tensor:
+    """fp32 table T[t+1] = abar(t), T[0] = abar(-1) = 1 -- the cumprod of utils/sampling.py:11-12, on the CPU."""
+    b = torch.cat([torch.zeros(1, dtype=torch.float32), betas.detach().float().cpu()], dim=0)
+    return (1 - b).cumprod(dim=0)
+
+
+def compute_alpha(beta, t):
+    """utils/sampling.py:10-13 (kept for API compatibility; t is a LongTensor)."""
+    beta = torch.cat([torch.zeros(1).to(beta.device), beta], dim=0)
+    return (1 - beta).cumprod(dim=0).index_select(0, t + 1).view(-1, 1, 1, 1)
+
+
+def overlapping_grid_indices(h, w, output_size, r=None):
+    """ddm_wavelet.py:426-435 on plain ints."""
+    r = 16 if r is None else r
+    h_list = [i for i in range(0, h - output_size + 1, r)]
+    w_list = [i for i in range(0, w - output_size + 1, r)]
+    if h_list[-1] + output_size < h:
+        h_list.append(h - output_size)
+    if w_list[-1] + output_size < w:
+        w_list.append(w - output_size)
+    return h_list, w_list
+
+
+def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all"):
+    """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
+
+    x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
+    corners: None -> every image is one p x p patch at (0,0) (p == H == W; the batched 64x64 case),
+             or a list of (hi, wi) applied to image 0 (the reference's stitched single-image case),
+             or a list of (img, hi, wi).
+    keep: "all" -> (xs, x0_preds) lists as the reference returns; or a set of negative indices into
+          x0_preds / xs to retain, e.g. {-5, -1} (saves nothing but list bookkeeping).
+    """
+    x = _lib.require_cuda_f32(x, "x")
+    x_cond = _lib.require_cuda_f32(x_cond, "x_cond")
+    x_other = _lib.require_cuda_f32(x_other, "x_other")
+    dev = x.device
+    L, h = _lib.lib(), _lib.handle(dev.index or 0)
+    nimg, pc, H, W = x.shape
+    ncond, nother = x_cond.shape[1], x_other.shape[1]
+    cin = unet.in_channels
+    assert ncond + pc + nother == cin, f"channel split {ncond}+{pc}+{nother} != UNet in_channels {cin}"
+    with torch.cuda.device(dev):
+        if corners is None:
+            p = H
+            assert H == W == unet.resolution
+            n, patches, pptr = nimg, None, None
+        else:
+            p = int(p_size)
+            tri = [(0, int(c[0]), int(c[1])) if len(c) == 2 else tuple(int(v) for v in c) for c in corners]
+            for (im, hi, wi) in tri:
+                if not (0 <= im < nimg and 0 <= hi and hi + p <= H and 0 <= wi and wi + p <= W):
+                    raise ValueError(f"patch {(im, hi, wi)} of size {p} outside the {nimg}x{H}x{W} image")
+            n = len(tri)
+            patches = torch.tensor(tri, dtype=torch.int32).to(dev)
+            pptr = _lib.ptr(patches)
+        assert p == unet.resolution, "patch size must equal config.data.image_size (unet.py:351)"
+        st = _lib.stream_ptr()
+        x96 = torch.empty(n, p, p, cin, device=dev, dtype=unet._torch_dtype)
+        _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
+        _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
+        eps = torch.empty(n, pc, p, p, device=dev, dtype=torch.float32)
+
+        seq = list(seq)
+        seq_next = [-1] + seq[:-1]
+        abar = alpha_bar_table(betas)
+        t_dev = torch.tensor([float(v) for v in reversed(seq)], dtype=torch.float32).to(dev)
+        xs, x0_preds = [x], []
+        xt = x
+        for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
+            at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
+            s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
+            san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
+            _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
+            for i in range(0, n, max_batch):
+                unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch])
+            x0 = torch.empty_like(x)
+            xn = torch.empty_like(x)
+            _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
+                                         _lib.ptr(x0), _lib.ptr(xn), st))
+            x0_preds.append(x0)
+            xs.append(xn)
+            xt = xn
+        if keep != "all":
+            S = len(x0_preds)
+            x0_preds = [t if (i - S) in keep else None for i, t in enumerate(x0_preds)]
+        return xs, x0_preds

@@ -1,0 +1,192 @@
+"""DiffusionUNet -- drop-in for the reference's `models/unet.py:196-395` whose forward runs on
+libwavedm_hip.so.
+
+* same constructor (`DiffusionUNet(config)` with the YAML namespace), same `state_dict()` keys
+  and tensor shapes (conv OIHW fp32, Linear [out,in]) so reference checkpoints load with
+  `load_state_dict(strict=True)`;
+* `forward(x, t)`: x (B, 96, R, R) fp32 NCHW on the GPU, t (n,) float with n in {1, B}
+  -> (B, 3, R, R) fp32 NCHW, exactly the reference call;
+* compute dtype: `config.model.hip_dtype` / env WAVEDM_DTYPE in {"bf16" (default), "f32"}.
+  f32 is the parity mode (exact-fp32 MFMA), bf16 the throughput mode (bf16 MFMA, fp32 accumulate).
+
+The parameter tree is generated from the library's own parameter table (wdm_unet_param_info), so
+Python and C++ cannot disagree about names or shapes."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .procedural import unet_in_channels
+
+
+class _Node(nn.Module):
+    """Anonymous container; children are named after the state_dict path components."""
+
+
+def _make_config(config, dtype_code):
+    m = config.model
+    cfg = _lib.UNetConfig()
+    cfg.ch = int(m.ch)
+    mult = list(m.ch_mult)
+    cfg.n_levels = len(mult)
+    for i, v in enumerate(mult):
+        cfg.ch_mult[i] = int(v)
+    cfg.num_res_blocks = int(m.num_res_blocks)
+    ar = list(m.attn_resolutions)
+    cfg.n_attn_res = len(ar)
+    for i, v in enumerate(ar):
+        cfg.attn_resolutions[i] = int(v)
+    cfg.in_channels = unet_in_channels(config)
+    cfg.out_ch = int(m.out_ch)
+    cfg.resolution = int(config.data.image_size)
+    cfg.resamp_with_conv = 1 if m.resamp_with_conv else 0
+    cfg.dtype = dtype_code
+    return cfg
+
+
+def resolve_dtype(config=None, dtype=None):
+    name = dtype or getattr(getattr(config, "model", None), "hip_dtype", None) or os.environ.get("WAVEDM_DTYPE", "bf16")
+    if name not in _lib.DTYPES:
+        raise ValueError(f"unknown compute dtype {name!r} (use 'bf16' or 'f32')")
+    return _lib.DTYPES[name]
+
+
+class DiffusionUNet(nn.Module):
+    def __init__(self, config, dtype=None):
+        super().__init__()
+        d = config.data
+        if getattr(d, "use_window", False) or getattr(d, "wavelet_in_unet", False) or getattr(d, "global_attn", False):
+            raise NotImplementedError("use_window / wavelet_in_unet / global_attn are off in raindrop_wavelet.yml and "
+                                      "outside the accelerated path (SURVEY.md §8f-4)")
+        self.config = config
+        self.resolution = int(d.image_size)
+        self.in_channels = unet_in_channels(config)
+        self.out_ch = int(config.model.out_ch)
+        self.ch = int(config.model.ch)
+        self.temb_ch = self.ch * 4
+        self._dtype_code = resolve_dtype(config, dtype)
+        self._torch_dtype = torch.bfloat16 if self._dtype_code == _lib.WDM_BF16 else torch.float32
+        L = _lib.lib()
+        self._cfg = _make_config(config, self._dtype_code)
+        u = C.c_void_p()
+        _lib.check(L.wdm_unet_create(None, C.byref(self._cfg), C.byref(u)))
+        self._u = u
+        self._names = []
+        name, ndim, shape = C.c_char_p(), C.c_int(), (C.c_int64 * 4)()
+        for i in range(L.wdm_unet_num_params(u)):
+            _lib.check(L.wdm_unet_param_info(u, i, C.byref(name), C.byref(ndim), C.byref(shape)))
+            key = name.value.decode()
+            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            self._names.append(key)
+            self._register(key, shp)
+        self._packed = None
+        self._packed_sig = None
+        self._ws = {}
+
+    # ---- parameter tree ------------------------------------------------------------------------
+    def _register(self, key, shape):
+        parts = key.split(".")
+        node = self
+        for comp in parts[:-1]:
+            if comp not in node._modules:
+                node.add_module(comp, _Node())
+            node = node._modules[comp]
+        p = torch.empty(shape, dtype=torch.float32)
+        leaf = parts[-1]
+        if len(shape) > 1:                                      # conv / linear weight: torch's default init
+            nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+        elif leaf == "weight" and ("norm" in parts[-2]):        # GroupNorm gamma
+            p.fill_(1.0)
+        elif leaf == "weight":
+            p.fill_(1.0)
+        else:
+            p.zero_()
+        node.register_parameter(leaf, nn.Parameter(p))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_u", None):
+                _lib.lib().wdm_unet_destroy(self._u)
+                self._u = None
+        except Exception:
+            pass
+
+    # ---- weights -> packed device buffer ---------------------------------------------------------
+    def packed_bytes(self):
+        return int(_lib.lib().wdm_unet_packed_bytes(self._u))
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def pack_weights(self, force=False):
+        """(Re)pack the fp32 parameters into the single device buffer the kernels read."""
+        sig = self._signature()
+        if not force and self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("DiffusionUNet: move the module to the GPU first (.to('cuda')); there is no CPU path")
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            if self._packed is None or self._packed.device != dev:
+                self._packed = torch.empty(self.packed_bytes() + 256, dtype=torch.uint8, device=dev)
+                _lib.check(L.wdm_unet_set_packed(self._u, _lib.ptr(self._packed), self._packed.numel()))
+            sd = dict(self.named_parameters())
+            for key in self._names:
+                src = sd[key].detach().contiguous()
+                _lib.check(L.wdm_unet_load_param(self._u, key.encode(), _lib.ptr(src), src.numel(), _lib.stream_ptr()))
+        self._packed_sig = sig
+        return self._packed
+
+    def adopt_packed(self):
+        """Declare the packed buffer valid after its bytes were filled externally (RCCL broadcast)."""
+        _lib.check(_lib.lib().wdm_unet_mark_loaded(self._u))
+        self._packed_sig = self._signature()
+
+    def alloc_packed(self, device):
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            self._packed = torch.empty(self.packed_bytes() + 256, dtype=torch.uint8, device=device)
+            _lib.check(L.wdm_unet_set_packed(self._u, _lib.ptr(self._packed), self._packed.numel()))
+        return self._packed
+
+    def workspace(self, B, device):
+        key = (B, str(device))
+        if key not in self._ws:
+            n = int(_lib.lib().wdm_unet_workspace_bytes(self._u, B))
+            if n == 0:
+                raise RuntimeError("wdm_unet_workspace_bytes failed: " + _lib.lib().wdm_last_error().decode())
+            self._ws = {key: torch.empty(n + 256, dtype=torch.uint8, device=device)}   # keep only the latest size
+        return self._ws[key]
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward_nhwc(self, x96, t, eps_out):
+        """x96: (B,R,R,Cin) NHWC in the compute dtype; t: (n,) fp32 device; eps_out: (B,out_ch,R,R) fp32."""
+        B = x96.shape[0]
+        assert x96.is_contiguous() and x96.dtype == self._torch_dtype and tuple(x96.shape[1:]) == (self.resolution, self.resolution, self.in_channels)
+        assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and tuple(eps_out.shape) == (B, self.out_ch, self.resolution, self.resolution)
+        assert t.dtype == torch.float32 and t.is_cuda and t.numel() in (1, B)
+        self.pack_weights()
+        with torch.cuda.device(x96.device):
+            ws = self.workspace(B, x96.device)
+            _lib.check(_lib.lib().wdm_unet_forward(self._u, _lib.ptr(x96), _lib.ptr(t), int(t.numel()), B, _lib.ptr(eps_out),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        return eps_out
+
+    def forward(self, x, t):
+        x = _lib.require_cuda_f32(x, "DiffusionUNet input")
+        B, Cc, H, W = x.shape
+        assert H == W == self.resolution, "input resolution != config.data.image_size (unet.py:351)"
+        assert Cc == self.in_channels and t.dim() == 1
+        L, h = _lib.lib(), _lib.handle(x.device.index or 0)
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            x96 = torch.empty(B, H, W, Cc, device=x.device, dtype=self._torch_dtype)
+            _lib.check(L.wdm_nchw_to_nhwc(h, _lib.ptr(x), _lib.ptr(x96), B, Cc, H, W, self._dtype_code, _lib.stream_ptr()))
+            eps = torch.empty(B, self.out_ch, H, W, device=x.device, dtype=torch.float32)
+            return self.forward_nhwc(x96, t, eps)
