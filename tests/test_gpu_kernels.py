@@ -152,10 +152,11 @@ def test_patch_gather_scatter_ddim(gu, O):
     cond = torch.randn(1, 48, H, W, generator=g)
     eps = torch.randn(n, 3, p, p, generator=g)
     pt = torch.tensor([(0, a, b) for a, b in corners], dtype=torch.int32).cuda()
+    cond_d, xt_d, eps_d = cond.cuda(), xt.cuda(), eps.cuda()       # keep device copies alive across the async launches
     # gather (integer-exact placement: values are copied, fp32 -> fp32)
     x96 = torch.zeros(n, p, p, 96, device="cuda")
-    _lib.check(L.wdm_pack_channels(h, _lib.ptr(cond.cuda()), 48, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 0, _lib.WDM_F32, _lib.stream_ptr()))
-    _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt.cuda()), 3, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 48, _lib.WDM_F32, _lib.stream_ptr()))
+    _lib.check(L.wdm_pack_channels(h, _lib.ptr(cond_d), 48, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 0, _lib.WDM_F32, _lib.stream_ptr()))
+    _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt_d), 3, H, W, _lib.ptr(pt), n, p, _lib.ptr(x96), 96, 48, _lib.WDM_F32, _lib.stream_ptr()))
     got = x96.cpu().permute(0, 3, 1, 2)
     for k, (hi, wi) in enumerate(corners):
         assert torch.equal(got[k, :48], cond[0, :, hi:hi + p, wi:wi + p])
@@ -171,11 +172,11 @@ def test_patch_gather_scatter_ddim(gu, O):
     x0w = (xt - et * (1 - at).sqrt()) / at.sqrt()
     xnw = an.sqrt() * x0w + (1 - an).sqrt() * et
     x0, xn = torch.empty(1, 3, H, W, device="cuda"), torch.empty(1, 3, H, W, device="cuda")
-    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps.cuda()), _lib.ptr(pt), n, p, _lib.ptr(xt.cuda()), 1, H, W, float((1 - at).sqrt()),
+    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps_d), _lib.ptr(pt), n, p, _lib.ptr(xt_d), 1, H, W, float((1 - at).sqrt()),
                                  float(at.sqrt()), float(an.sqrt()), float((1 - an).sqrt()), _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
     assert rel_linf(x0.cpu(), x0w) <= 1e-6 and rel_linf(xn.cpu(), xnw) <= 1e-6
     # uncovered pixels -> NaN like the reference's 0/0
     pt2 = torch.tensor([(0, 0, 0)], dtype=torch.int32).cuda()
-    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps.cuda()), _lib.ptr(pt2), 1, p, _lib.ptr(xt.cuda()), 1, H, W, 0.5, 0.5, 0.5, 0.5,
+    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps_d), _lib.ptr(pt2), 1, p, _lib.ptr(xt_d), 1, H, W, 0.5, 0.5, 0.5, 0.5,
                                  _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
     assert torch.isnan(x0.cpu()[0, 0, H - 1, W - 1]) and not torch.isnan(x0.cpu()[0, 0, 0, 0])

@@ -29,10 +29,6 @@ def inverse_data_transform(X):     # ddm_wavelet.py:31-32
     return torch.clamp((X + 1.0) / 2.0, 0.0, 1.0)
 
 
-class _Unwrapped(torch.nn.Module):
-    """Gives `.module` (as DDP would) without wrapping anything."""
-
-
 class DenoisingDiffusion_Wavelet(object):
     def __init__(self, args, config, generator=None, dtype=None, verbose=False):
         super().__init__()
@@ -50,7 +46,6 @@ class DenoisingDiffusion_Wavelet(object):
         if getattr(config.data, "global_attn", False):
             raise NotImplementedError("data.global_attn=True (DiffusionUNet_Global) is outside the accelerated path")
         self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
-        self.model.module = self.model          # callers written for the DDP-wrapped model keep working
         self.start_epoch, self.step = 0, 0
         self.ema_shadow = None
 

@@ -88,6 +88,12 @@ class DiffusionUNet(nn.Module):
         self._packed_sig = None
         self._ws = {}
 
+    @property
+    def module(self):
+        """The reference wraps the UNet in DistributedDataParallel and callers unwrap with `.module`
+        (ddm_wavelet.py:286); inference needs no DDP, so `.module` is the model itself."""
+        return self
+
     # ---- parameter tree ------------------------------------------------------------------------
     def _register(self, key, shape):
         parts = key.split(".")
