@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: restored images/sec, raindrop 64x64 patches, 100-step DDIM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank: DWT of the
+rainy crops and of the HFRM stand-in (B,3,256,256) -> S=100 DDIM steps of the wavelet-domain UNet
+on (B,96,64,64) -> IDWT of the restored sub-bands, inputs resident in HBM when the clock starts.
+Workload at N=1 = BASELINE.json configs[1] (raindrop_wavelet 64x64, batch 64, 100 DDIM steps, bf16);
+N>1 shards independent images: every rank runs its own batch of 64 (weak scaling, configs[3]),
+weights are packed on rank 0 and broadcast over RCCL, outputs are all-gathered after the clock stops.
+
+Prints ONE JSON line on rank 0 (see README / the driver contract) including
+  roofline      live HIP-event timing of the dominant kernel (the fused 3x3 implicit-GEMM conv) inside this run
+  cpu_baseline  the CPU oracle timed on this box's host cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE configs[1]: 64)")
+    ap.add_argument("--ddim-steps", type=int, default=100)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    torch.set_grad_enabled(False)
+
+    from types import SimpleNamespace
+    import wavedm_amd
+    from wavedm_amd import _lib, parallel
+    from wavedm_amd import procedural as P
+
+    cfg = P.raindrop_wavelet_config()
+    cfg.device = dev
+    a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_rank, image_folder="/tmp/wdm",
+                        test_set="raindrop", grid_r=16, max_batch=args.batch)
+    t0 = time.time()
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, dtype=args.dtype)
+    sd = None
+    if rank == 0:
+        sd = P.procedural_state_dict(cfg, seed=61)          # random-init weights of the named architecture
+        d.model.load_state_dict(sd, strict=True)
+        d.model.pack_weights()
+    if world > 1:
+        parallel.broadcast_weights(d.model, src=0)           # 324 MB packed buffer over RCCL/xGMI, once
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] model ready in {time.time() - t0:.1f}s ({sum(p.numel() for p in d.model.parameters()) / 1e6:.2f} M params, "
+            f"packed {d.model.packed_bytes() / 1e6:.0f} MB, dtype {args.dtype})")
+
+    B = args.batch
+    rainy, x_T = P.synthetic_batch(B, patch_px=256, seed=61 + rank)
+    rainy, x_T = rainy.to(dev), x_T.to(dev)
+
+    def one_pass():
+        return d.restore_batch(rainy, x_T)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out, xs_last, x0 = one_pass()
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        gathered = parallel.all_gather_shards(out, B * world)          # outside the timed region
+        assert gathered.shape[0] == B * world
+    finite = bool(torch.isfinite(out).all())
+
+    # ---- roofline leg: one more pass of the SAME workload with HIP events around every conv launch
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        _lib.prof_enable(True)
+        one_pass()
+        torch.cuda.synchronize()
+        rep = _lib.prof_report()
+        _lib.prof_enable(False)
+        rep.sort(key=lambda e: -e["ms"])
+        tot_ms = sum(e["ms"] for e in rep)
+        for e in rep:
+            log(f"[bench] {e['kernel']:<36s} launches {e['launches']:6d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  "
+                f"{e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  {e['bytes'] / e['ms'] / 1e6:7.1f} GB/s(alg)  {100 * e['ms'] / tot_ms:5.1f}% of conv time")
+        dom = rep[0]
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        ach = dom["flops"] / dom["ms"] / 1e9
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "kernel": dom["kernel"], "launches": dom["launches"],
+                    "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "all_conv_tflops": round(sum(e["flops"] for e in rep) / tot_ms / 1e9, 2),
+                    "conv_ms_per_pass": round(tot_ms, 2)}
+
+    # ---- CPU baseline leg: the oracle on this box's host cores, bounded sample (BASELINE configs[0])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import wavedm_oracle as O
+        nb, ns = 4, 10
+        r4, xt4 = P.synthetic_batch(nb, patch_px=256, seed=61)
+        xc = O.dwt_fwd(2 * r4 - 1)
+        # pick the thread count that serves this small batch best (oneDNN on a 256-thread host is slower with all
+        # threads than with a NUMA-domain-sized team), then time the bounded sample with it
+        best_n, best_t = torch.get_num_threads(), None
+        for nthr in sorted({8, 16, 32, 64, torch.get_num_threads()}):
+            if nthr > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(nthr)
+            O.ddim_batch(sd, cfg, xt4, xc, xc[:, 3:].contiguous(), 1, chunk=nb)      # 1 step (warm-up + probe)
+            tp = time.perf_counter()
+            O.ddim_batch(sd, cfg, xt4, xc, xc[:, 3:].contiguous(), 1, chunk=nb)
+            tp = time.perf_counter() - tp
+            log(f"[bench] cpu oracle probe: {nthr} threads -> {tp:.2f} s per {nb}-image step")
+            if best_t is None or tp < best_t:
+                best_n, best_t = nthr, tp
+        torch.set_num_threads(best_n)
+        tc = time.perf_counter()
+        O.ddim_batch(sd, cfg, xt4, xc, xc[:, 3:].contiguous(), ns, chunk=nb)
+        tcpu = time.perf_counter() - tc
+        cpu_ips = nb / (tcpu * args.ddim_steps / ns)
+        cpu = {"value": round(cpu_ips, 5), "unit": "img/s", "cores": best_n, "kind": "port",
+               "sample": f"{nb} images x {ns} DDIM steps of the torch-CPU oracle (fp32, oneDNN) = {tcpu:.1f} s, scaled x{args.ddim_steps // ns} to {args.ddim_steps} steps",
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        total_imgs = B * world * args.steps
+        res = {
+            "metric": "restored images/sec, raindrop 64x64 patches, 100-step DDIM",
+            "value": round(total_imgs / elapsed, 3),
+            "unit": "img/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (seeded U[0,1) 256x256 crops, procedural random-init weights of the raindrop_wavelet UNet)",
+            "config": {"workload": f"raindrop_wavelet 64x64 (256x256 px crops), batch {B}/GPU, {args.ddim_steps} DDIM steps, "
+                                   f"DWT + UNet x{args.ddim_steps} + IDWT (BASELINE.json configs[1]{' x N, configs[3]' if world > 1 else ''})",
+                       "global_batch": B * world, "ddim_steps": args.ddim_steps, "parallelism": f"image-sharded x{world}",
+                       "outputs_finite": finite},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            res["speedup_vs_cpu"] = round(res["value"] / cpu["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,18 @@ int wdm_temb_forward(wdm_handle* h, const float* t, int n_t, int ch, const float
                      const float* w1, const float* b1, float* temb_out, void* scratch, size_t scratch_bytes,
                      void* stream);
 
+/* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
+ * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
+ * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).
+ * wdm_prof_report synchronises those events, aggregates per kernel configuration and clears. */
+typedef struct wdm_prof_entry {
+    char kernel[96];
+    long long launches;
+    double total_ms, total_flops, total_bytes;
+} wdm_prof_entry;
+int wdm_prof_enable(int on);
+int wdm_prof_report(wdm_prof_entry* out, int max_entries, int* n_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 output directories to small per-kernel summaries (committed under profiles/).
+
+    python scripts/summarize_rocprof.py stats  <dir> <out.md>     # --kernel-trace --stats run
+    python scripts/summarize_rocprof.py pmc    <dir> <out.json>   # --pmc run (one or more counters)
+
+Kernel names are shortened to the template arguments that identify a conv configuration."""
+import glob
+import json
+import os
+import re
+import sys
+
+import pandas as pd
+
+
+def short(name: str) -> str:
+    """Mangled kernel name (rocprofv3 -M) -> readable id; conv_kernel<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>."""
+    m = re.search(r"conv_kernelI(DF16b|f)((?:Li\d+E)+)", name)
+    if m:
+        a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(2))]
+        if len(a) == 8:
+            mode = {0: "3x3s1", 1: "3x3s2", 2: "3x3ups", 3: "1x1"}[a[0]]
+            ty = "bf16" if m.group(1) == "DF16b" else "f32"
+            return f"conv_{mode}_t{a[1]}x{a[2]}x{a[3]}_bn{16 * a[7] * a[5]}_{ty}"
+    m = re.match(r"_ZN3wdm\d+([A-Za-z0-9_]+?)(?:I|E)", name)
+    if m:
+        return m.group(1)
+    m = re.match(r"(?:void )?(?:wdm::)?([A-Za-z0-9_]+)", name)
+    return m.group(1) if m else name[:60]
+
+
+def find(d, pat):
+    fs = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    if not fs:
+        raise SystemExit(f"no {pat} under {d}")
+    return fs
+
+
+def stats(d, out):
+    rows = []
+    for f in find(d, "*kernel_trace.csv"):
+        rows.append(pd.read_csv(f))
+    df = pd.concat(rows)
+    df["k"] = df["Kernel_Name"].map(short)
+    df["dur_us"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
+    g = df.groupby("k")["dur_us"].agg(["count", "sum", "mean", "min", "max"]).sort_values("sum", ascending=False)
+    tot = g["sum"].sum()
+    with open(out, "w") as fh:
+        fh.write(f"rocprofv3 --kernel-trace --stats summary ({len(df)} dispatches, {tot / 1e6:.3f} s of kernel time)\n\n")
+        fh.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for k, r in g.iterrows():
+            fh.write(f"| {k} | {int(r['count'])} | {r['sum'] / 1e3:.2f} | {r['mean']:.2f} | {r['min']:.2f} | {r['max']:.2f} | {100 * r['sum'] / tot:.2f} |\n")
+        extra = [c for c in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size") if c in df.columns]
+        if extra:
+            fh.write("\nresources per kernel (first dispatch):\n\n| kernel | " + " | ".join(extra) + " | grid | wg |\n|---|" + "---|" * (len(extra) + 2) + "\n")
+            for k in g.index:
+                r = df[df["k"] == k].iloc[0]
+                fh.write(f"| {k} | " + " | ".join(str(r[c]) for c in extra) + f" | {r.get('Grid_Size_X', r.get('Grid_Size', ''))} | {r.get('Workgroup_Size_X', r.get('Workgroup_Size', ''))} |\n")
+    print(open(out).read())
+
+
+def pmc(d, out):
+    rows = []
+    for f in find(d, "*counter_collection.csv"):
+        rows.append(pd.read_csv(f))
+    df = pd.concat(rows)
+    df["k"] = df["Kernel_Name"].map(short)
+    piv = df.pivot_table(index=["k", "Dispatch_Id"], columns="Counter_Name", values="Counter_Value", aggfunc="sum").reset_index()
+    res = {}
+    for k, g in piv.groupby("k"):
+        ent = {"dispatches": int(len(g))}
+        for c in g.columns:
+            if c in ("k", "Dispatch_Id"):
+                continue
+            ent[c] = {"sum": float(g[c].sum()), "mean_per_dispatch": float(g[c].mean())}
+        res[k] = ent
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True)[:6000])
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -29,6 +29,11 @@ class ResblockParams(C.Structure):
         "nin_w", "nin_b")]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 96), ("launches", C.c_longlong), ("total_ms", C.c_double),
+                ("total_flops", C.c_double), ("total_bytes", C.c_double)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("c", C.c_int)] + [(n, C.c_void_p) for n in (
         "norm_w", "norm_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj_w", "proj_b")]
@@ -70,6 +75,8 @@ def lib():
         "wdm_attn_forward": (i, [vp, C.POINTER(AttnParams), vp, i, i, i, vp, i, vp, sz, vp]),
         "wdm_conv_forward": (i, [vp, vp, vp, i, i, i, vp, i, i, i, vp, i, vp, sz, vp]),
         "wdm_temb_forward": (i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "wdm_prof_enable": (i, [i]),
+        "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = header / library mismatch: fail loudly
@@ -84,7 +91,21 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_pack_channels", "wdm_ddim_update", "wdm_nchw_to_nhwc", "wdm_nhwc_to_nchw", "wdm_unet_create",
             "wdm_unet_destroy", "wdm_unet_num_params", "wdm_unet_param_info", "wdm_unet_packed_bytes",
             "wdm_unet_set_packed", "wdm_unet_load_param", "wdm_unet_mark_loaded", "wdm_unet_workspace_bytes",
-            "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward"]
+            "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
+            "wdm_prof_enable", "wdm_prof_report"]
+
+
+def prof_enable(on: bool):
+    check(lib().wdm_prof_enable(1 if on else 0))
+
+
+def prof_report():
+    """-> list of dicts {kernel, launches, ms, flops, bytes} aggregated since the last report."""
+    arr = (ProfEntry * 64)()
+    n = C.c_int()
+    check(lib().wdm_prof_report(arr, 64, C.byref(n)))
+    return [dict(kernel=arr[k].kernel.decode(), launches=int(arr[k].launches), ms=float(arr[k].total_ms),
+                 flops=float(arr[k].total_flops), bytes=float(arr[k].total_bytes)) for k in range(n.value)]
 
 
 def check(rc: int):

@@ -126,6 +126,11 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
                 int dtype, hipStream_t s);
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
 
+// ---- live kernel timing (prof.hip): HIP events on the launch stream around every conv launch ------
+bool prof_enabled();
+void prof_begin(hipStream_t s, const char* kernel, double flops, double bytes);
+void prof_end(hipStream_t s);
+
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 

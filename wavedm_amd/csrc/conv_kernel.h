@@ -18,10 +18,15 @@
 // K = taps x Cin.  Activations are NHWC so the K (channel) axis is contiguous for both operands
 // (weights are packed [tap][cout][cin]): every MFMA fragment is one 16-byte LDS read per lane.
 //
-// LDS image (both operands):   [k-unit (4)][row slot][16 bytes]
-//   a "unit" is 16 bytes of consecutive channels (8 bf16 / 4 f32); lane l of a wave reads unit (l>>4) of row
-//   (l&15) -> the 16 lanes of a ds_read_b128 service group touch 16 consecutive 16-byte slots: conflict-free.
-//   The unit planes are padded to a multiple of 16 slots so every unit has the same bank phase.
+// LDS image (both operands):   [row slot q][4 k-units, rotated][16 bytes]   -- 64 bytes per pixel / weight row
+//   a "unit" is 16 bytes of consecutive channels (8 bf16 / 4 f32); unit u of row q lives in 16-byte slot
+//   4q + (u ^ ((q>>1)&2)).  Lane l of a wave reads unit (l>>4) of row base+(l&15).  With that rotation
+//     * ds_read_b128 (16-lane service groups {0-3,12-15,20-27}, ..., banks = 16 slots of 16 B): the 8 lanes of a
+//       group that share a unit cover every (q&3) twice with opposite ((q>>2)&1) -> 8 distinct slots, and the two
+//       units of a group differ in parity -> all 16 distinct for ANY base row (taps shift the base): conflict-free;
+//     * ds_write_b128 (8 contiguous lanes = 2 pixels x 4 units = one 128-byte bank row): conflict-free.
+//   (The first version used [unit][row][16 B]: conflict-free reads but 4-way conflicts on every staging store;
+//   rocprofv3 showed SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.46 -- see profiles/.)
 //   bf16: one v_mfma_f32_16x16x32_bf16 consumes the 4 units (K = 32);  f32 (parity mode): four
 //   v_mfma_f32_16x16x4_f32, MFMA j taking element j of every unit (K = 16) -- exact fp32 FMA chains.
 //
@@ -108,8 +113,9 @@ template <> struct TI<__bf16> {
 };
 
 __device__ __forceinline__ float silu_f(float v) {
-    // x * sigmoid(x) = x / (1 + e^-x)   (unet.py:31-33)
-    return v / (1.0f + __expf(-v));
+    // x * sigmoid(x) = x / (1 + e^-x)   (unet.py:31-33); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE divide:
+    // this runs once per staged element in the conv prologue, where VALU issue slots compete with the MFMA stream
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
@@ -126,7 +132,7 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 // ------------------------------------------------------------------------------------------------
 // compile-time geometry of one kernel configuration
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, int KSUB = 4>
 struct ConvCfg {
     static constexpr int NTHREADS = 256;
     static constexpr int VEC = TI<T>::VEC;
@@ -134,18 +140,19 @@ struct ConvCfg {
     static constexpr int BK = NU * VEC;          // channels per slab: 32 (bf16) / 16 (f32)
     static constexpr int M = TH * TW * NI;
     static constexpr int BN = 16 * WN * WAVES_N;
-    static constexpr int NSUB = (MODE == MODE_P1) ? 4 : 9;   // B sub-blocks per stage (taps, or slabs for 1x1)
-    static constexpr int NSUBA = (MODE == MODE_P1) ? 4 : 1;  // A sub-planes per stage
+    static constexpr int NSUB = (MODE == MODE_P1) ? KSUB : 9;   // B sub-blocks per stage (taps, or slabs for 1x1)
+    static constexpr int NSUBA = (MODE == MODE_P1) ? KSUB : 1;  // A sub-planes per stage
     static constexpr int PH = MODE == MODE_S1 ? TH + 2 : MODE == MODE_S2 ? 2 * TH + 1 : MODE == MODE_UPS ? TH / 2 + 2 : TH;
     static constexpr int PW = MODE == MODE_S1 ? TW + 2 : MODE == MODE_S2 ? 2 * TW + 1 : MODE == MODE_UPS ? TW / 2 + 2 : TW;
-    // row stride in slots: for 8-wide tiles a 16-row MFMA group spans two image rows; stride == 8 (mod 16)
-    // keeps its 16 slots distinct modulo 16
-    static constexpr int RS = (TW == 8 && MODE == MODE_S1) ? 24 : PW;
-    static constexpr int NPIX = PH * PW;
-    static constexpr int PLANE_IMG = PH * RS;
-    static constexpr int PLANE = ((NI * PLANE_IMG + 15) / 16) * 16;
-    static constexpr int A_BYTES = NSUBA * NU * PLANE * 16;
-    static constexpr int B_BYTES = NSUB * NU * BN * 16;
+    // row stride in pixel slots, a multiple of 8: (a) a tap's dy*RS never changes the rotation bit (q>>2)&1, so
+    // only the three dx variants of a fragment address are kept in registers; (b) for 8-wide tiles a 16-row MFMA
+    // group spans two image rows RS apart and stays conflict-free
+    static constexpr int RS = (PW + 7) / 8 * 8;
+    static constexpr int NPIX = PH * PW;                      // pixels actually staged per image
+    static constexpr int PLANE_IMG = PH * RS;                 // pixel slots per image
+    static constexpr int PLANE = NI * PLANE_IMG;              // pixel slots per A sub-plane
+    static constexpr int A_BYTES = NSUBA * PLANE * 64;
+    static constexpr int B_BYTES = NSUB * BN * 64;
     static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
     static constexpr int A_IPI = (NSUBA * NPIX * NU + NTHREADS - 1) / NTHREADS;   // A items per thread per image
     static constexpr int B_IPT = (NSUB * BN * NU + NTHREADS - 1) / NTHREADS;      // B items per thread
@@ -155,16 +162,20 @@ struct ConvCfg {
     static_assert(NI == 1 || (MODE == MODE_S1 || MODE == MODE_P1), "multi-image tiles: s1 / 1x1 only");
 };
 
+// byte offset of unit u of row slot q inside an operand image (see the header comment)
+__device__ __forceinline__ int lds_off(int q, int u) { return (q << 6) | ((u ^ ((q >> 1) & 2)) << 4); }
+
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, int KSUB = 4>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
-    using C = ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
+    using C = ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>;
     constexpr int VEC = C::VEC, NU = C::NU, BK = C::BK, BN = C::BN;
     constexpr int NSUB = C::NSUB, NSUBA = C::NSUBA, PW = C::PW, RS = C::RS, NPIX = C::NPIX;
     constexpr int PLANE = C::PLANE, PLANE_IMG = C::PLANE_IMG, A_BYTES = C::A_BYTES;
     constexpr int A_IPI = C::A_IPI, B_IPT = C::B_IPT;
+    constexpr int NDX = (MODE == MODE_S1 || MODE == MODE_S2) ? 3 : 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -197,23 +208,26 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     const int iy0 = MODE == MODE_S1 ? oy0 - 1 : MODE == MODE_S2 ? 2 * oy0 : MODE == MODE_UPS ? (oy0 >> 1) - 1 : oy0;
     const int ix0 = MODE == MODE_S1 ? ox0 - 1 : MODE == MODE_S2 ? 2 * ox0 : MODE == MODE_UPS ? (ox0 >> 1) - 1 : ox0;
 
-    // ---- per-lane fragment addresses (bytes into smem)
-    int a_addr[WM];
+    // ---- per-lane fragment addresses (bytes into smem).  A: one address per dx (the rotation bit depends on the
+    // row slot), dy and the sub-plane are immediate offsets.
+    const int ku = lane >> 4;                  // k-unit this lane feeds to the MFMA
+    int a_addr[WM][NDX];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int m = (wave_m * WM + i) * 16 + (lane & 15);
         const int img = m / (TH * TW), r = m % (TH * TW);
         const int ly = r / TW, lx = r % TW;
-        int slot;
-        if (MODE == MODE_S2) slot = img * PLANE_IMG + 2 * ly * RS + 2 * lx;
-        else if (MODE == MODE_UPS) slot = (ly << 8) | lx;      // resolved per tap below
-        else slot = img * PLANE_IMG + ly * RS + lx;
-        a_addr[i] = (MODE == MODE_UPS) ? slot : ((lane >> 4) * PLANE + slot) * 16;
+        if (MODE == MODE_UPS) {
+            a_addr[i][0] = (ly << 8) | lx;     // resolved per tap in compute_stage
+        } else {
+            const int q0 = img * PLANE_IMG + (MODE == MODE_S2 ? 2 * ly * RS + 2 * lx : ly * RS + lx);
+#pragma unroll
+            for (int dx = 0; dx < NDX; ++dx) a_addr[i][dx] = lds_off(q0 + dx, ku);
+        }
     }
     int b_addr[WN];
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
-        b_addr[j] = A_BYTES + ((lane >> 4) * BN + (wave_n * WN + j) * 16 + (lane & 15)) * 16;
+    for (int j = 0; j < WN; ++j) b_addr[j] = A_BYTES + lds_off((wave_n * WN + j) * 16 + (lane & 15), ku);
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
 
     auto load_stage = [&](int st) __attribute__((always_inline)) {
         const int cbase = (MODE == MODE_P1) ? st * NSUB * BK : st * BK;
-        // ---- A items
+        // ---- A items: thread -> (pixel = tid>>2 + 64 i, unit = tid&3): a quad of lanes reads one pixel's 64 bytes
 #pragma unroll
         for (int im = 0; im < NI; ++im) {
             const int img_g = img0 + im;
@@ -291,27 +305,29 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     };
 
     auto store_stage = [&]() __attribute__((always_inline)) {
+        const bool pro = (MODE == MODE_S1) && a.pro;
 #pragma unroll
         for (int im = 0; im < NI; ++im) {
 #pragma unroll
             for (int i = 0; i < A_IPI; ++i) {
                 const int pq = (tid >> 2) + i * (C::NTHREADS / NU);
-                if (pq < NSUBA * NPIX) {
+                constexpr int LIMIT = NSUBA * NPIX;
+                const bool may_overrun = (i + 1) * (C::NTHREADS / NU) > LIMIT;   // compile-time per unrolled i
+                if (!may_overrun || pq < LIMIT) {
                     const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
                     const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
                     const int hy = q / PW, hx = q - hy * PW;
                     uint4 v = ra[im][i];
-                    if (MODE == MODE_S1) {
-                        if (a.pro && ((inb_mask >> (im * A_IPI + i)) & 1u)) {
-                            float f[VEC];
-                            TI<T>::unpack(v, f);
+                    if (pro) {       // wave-uniform; out-of-image pixels stay zero (padding comes AFTER the activation)
+                        float f[VEC];
+                        TI<T>::unpack(v, f);
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) f[e] = silu_f(f[e] * sc[im][e] + sh[im][e]);
-                            v = TI<T>::pack(f);
-                        }
+                        for (int e = 0; e < VEC; ++e) f[e] = silu_f(f[e] * sc[im][e] + sh[im][e]);
+                        const uint4 tv = TI<T>::pack(f);
+                        const bool in = (inb_mask >> (im * A_IPI + i)) & 1u;
+                        v.x = in ? tv.x : 0u; v.y = in ? tv.y : 0u; v.z = in ? tv.z : 0u; v.w = in ? tv.w : 0u;
                     }
-                    const int off = (((sub * NU + unit) * PLANE) + im * PLANE_IMG + hy * RS + hx) * 16;
-                    *(uint4*)(smem + off) = v;
+                    *(uint4*)(smem + sub * (PLANE * 64) + lds_off(im * PLANE_IMG + hy * RS + hx, unit)) = v;
                 }
             }
         }
@@ -319,7 +335,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
         for (int i = 0; i < B_IPT; ++i) {
             const int rn = (tid >> 2) + i * (C::NTHREADS / NU);
             const int sub = rn / BN, n = rn % BN;
-            if (sub < NSUB) *(uint4*)(smem + A_BYTES + (((sub * NU + unit) * BN) + n) * 16) = rb[i];
+            const bool may_overrun = (i + 1) * (C::NTHREADS / NU) > NSUB * BN;
+            if (!may_overrun || sub < NSUB) *(uint4*)(smem + A_BYTES + sub * (BN * 64) + lds_off(n, unit)) = rb[i];
         }
     };
 
@@ -333,19 +350,19 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 int off;
-                if (MODE == MODE_P1) off = a_addr[i] + s * NU * PLANE * 16;
+                if (MODE == MODE_P1) off = a_addr[i][0] + s * (PLANE * 64);
                 else if (MODE == MODE_UPS) {
                     const int dy = s / 3, dx = s % 3;
-                    const int ly = a_addr[i] >> 8, lx = a_addr[i] & 255;
-                    off = ((lane >> 4) * PLANE + ((ly + dy + 1) >> 1) * RS + ((lx + dx + 1) >> 1)) * 16;
+                    const int ly = a_addr[i][0] >> 8, lx = a_addr[i][0] & 255;
+                    off = lds_off(((ly + dy + 1) >> 1) * RS + ((lx + dx + 1) >> 1), ku);
                 } else {
                     const int dy = s / 3, dx = s % 3;
-                    off = a_addr[i] + (dy * RS + dx) * 16;
+                    off = a_addr[i][dx % NDX] + dy * (RS * 64);
                 }
                 af[i] = *(const uint4*)(smem + off);
             }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(smem + b_addr[j] + s * NU * BN * 16);
+            for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(smem + b_addr[j] + s * (BN * 64));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -396,10 +413,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     }
 }
 
-// host-side launcher implemented per dtype in conv_bf16.hip / conv_f32.hip
+// host-side launchers implemented per dtype in conv_bf16.hip / conv_f32.hip
 int launch_conv_bf16(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32(const ConvArgs& a, int mode, hipStream_t s);
-
-
 
 }  // namespace wdm
