@@ -157,6 +157,8 @@ struct ConvCfg {
     static constexpr int A_IPI = (NSUBA * NPIX * NU + NTHREADS - 1) / NTHREADS;   // A items per thread per image
     static constexpr int B_IPT = (NSUB * BN * NU + NTHREADS - 1) / NTHREADS;      // B items per thread
     static constexpr bool PREFETCH = (MODE != MODE_S2);   // S2 tiles stage 4x the pixels: keep registers low
+    // two workgroups per CU (one's LDS-fill phase overlaps the other's MFMA phase) need <= 256 registers per lane
+    static constexpr int MIN_WAVES = (LDS_BYTES <= 80 * 1024 && MODE != MODE_P1) ? 2 : 1;
     static_assert(M == 16 * WM * WAVES_M, "tile M mismatch");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(NI == 1 || (MODE == MODE_S1 || MODE == MODE_P1), "multi-image tiles: s1 / 1x1 only");
@@ -169,7 +171,7 @@ __device__ __forceinline__ int lds_off(int q, int u) { return (q << 6) | ((u ^ (
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, int KSUB = 4>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>::MIN_WAVES)) void conv_kernel(const ConvArgs a) {
     using C = ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>;
     constexpr int VEC = C::VEC, NU = C::NU, BK = C::BK, BN = C::BN;
     constexpr int NSUB = C::NSUB, NSUBA = C::NSUBA, PW = C::PW, RS = C::RS, NPIX = C::NPIX;
@@ -381,32 +383,102 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
         compute_stage(st);
     }
 
-    // ---- epilogue
-    const int ncol = lane & 15;
+    // ---- epilogue: accumulators -> per-wave LDS tile (fp32) -> row-contiguous 16-byte global accesses.
+    // The MFMA C layout gives a lane ONE channel of 4 pixels; storing from it directly costs one 2-byte store per
+    // output (64 store instructions per lane, issue-bound).  Through LDS every lane owns 8 consecutive channels of
+    // one pixel: alpha*acc + bias + temb + residual in fp32, then one 16-byte store (and one 16-byte residual load).
+    {
+        constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
+        constexpr int ECOLS = 16 * NJ;
+        constexpr int ESTR = ECOLS + 4;                   // row stride (floats): 4*ESTR = 16 (mod 32) -> conflict-free writes
+        constexpr int EROWS = 16 * WM;
+        constexpr int LPR = ECOLS / 8;                    // lanes per row
+        constexpr int RPI = 64 / LPR;                     // rows per iteration
+        static_assert(4 * EROWS * ESTR * 4 <= C::LDS_BYTES, "epilogue tile does not fit in LDS");
+        float* ep = (float*)smem + wave * (EROWS * ESTR);
+        const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + (wave_n * WN + j) * 16 + ncol;
-        const bool nok = n < a.Cout;
-        const float bj = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+        for (int jp = 0; jp < WN; jp += NJ) {
+            __syncthreads();                              // main loop / previous pass finished with this LDS
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = (wave_m * WM + i) * 16 + (lane >> 4) * 4 + r;
-                const int img = m / (TH * TW), rr = m % (TH * TW);
-                const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
-                const int img_g = img0 + img;
-                if (!nok || img_g >= a.B) continue;
-                float v = acc[i][j][r] * a.alpha + bj;
-                if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
-                const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
-                if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
-                if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
-                else if (a.y_mode == Y_NHWC_F32) ((float*)a.y)[opix * a.y_s + n] = v;
-                else {
-                    const long long o = (((long long)img_g * a.Cout + n) * a.Hout + oy) * a.Wout + ox;
-                    if (a.y_mode == Y_NCHW) TI<T>::st(a.y, o, v);
-                    else ((float*)a.y)[o] = v;
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
+            __syncthreads();
+            const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
+            if (vec_ok) {
+                const int c8 = (lane % LPR) * 8;
+                const int n = ncol0 + c8;
+                float bias8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias8[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+#pragma unroll
+                for (int it = 0; it < EROWS / RPI; ++it) {
+                    const int rloc = it * RPI + lane / LPR;
+                    const int m = wave_m * EROWS + rloc;
+                    const int img = m / (TH * TW), rr = m % (TH * TW);
+                    const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
+                    const int img_g = img0 + img;
+                    if (n >= a.Cout || img_g >= a.B) continue;
+                    const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
+                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
+                    if (a.temb != nullptr) {
+                        const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
+                        const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
+                        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                    }
+                    const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+                    if (a.res != nullptr) {
+                        float rf[8];
+                        const T* rp = (const T*)a.res + opix * a.res_s + n;
+                        if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
+                        else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                    }
+                    if (a.y_mode == Y_NHWC) {
+                        T* yp = (T*)a.y + opix * a.y_s + n;
+                        if (VEC == 8) { *(uint4*)yp = TI<T>::pack(v); }
+                        else { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
+                    } else {
+                        float* yp = (float*)a.y + opix * a.y_s + n;
+                        *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            } else {
+                // channel-major (NCHW) outputs and odd channel counts: lane = pixel row, loop over channels, so that
+                // for each channel the 64 lanes write runs of consecutive pixels
+#pragma unroll 1
+                for (int it = 0; it < (EROWS + 63) / 64; ++it) {
+                    const int rloc = it * 64 + lane;
+                    if (rloc >= EROWS) continue;
+                    const int m = wave_m * EROWS + rloc;
+                    const int img = m / (TH * TW), rr = m % (TH * TW);
+                    const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
+                    const int img_g = img0 + img;
+                    if (img_g >= a.B) continue;
+                    const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+#pragma unroll 4
+                    for (int c = 0; c < ECOLS; ++c) {
+                        const int n = ncol0 + c;
+                        if (n >= a.Cout) break;
+                        float v = ep[rloc * ESTR + c] * a.alpha + (a.bias != nullptr ? a.bias[n] : 0.f);
+                        if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
+                        if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
+                        if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
+                        else if (a.y_mode == Y_NHWC_F32) ((float*)a.y)[opix * a.y_s + n] = v;
+                        else {
+                            const long long o = (((long long)img_g * a.Cout + n) * a.Hout + oy) * a.Wout + ox;
+                            if (a.y_mode == Y_NCHW) TI<T>::st(a.y, o, v);
+                            else ((float*)a.y)[o] = v;
+                        }
+                    }
                 }
             }
         }
