@@ -119,13 +119,22 @@ def main():
         _lib.prof_enable(True)
         one_pass()
         torch.cuda.synchronize()
-        rep = _lib.prof_report()
+        shapes = _lib.prof_report()                        # one row per (kernel configuration | layer shape)
         _lib.prof_enable(False)
-        rep.sort(key=lambda e: -e["ms"])
+        agg = {}
+        for e in shapes:
+            k = e["kernel"].split("|")[0]
+            r = agg.setdefault(k, dict(kernel=k, launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            for f in ("launches", "ms", "flops", "bytes"):
+                r[f] += e[f]
+        rep = sorted(agg.values(), key=lambda e: -e["ms"])
         tot_ms = sum(e["ms"] for e in rep)
         for e in rep:
             log(f"[bench] {e['kernel']:<36s} launches {e['launches']:6d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  "
                 f"{e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  {e['bytes'] / e['ms'] / 1e6:7.1f} GB/s(alg)  {100 * e['ms'] / tot_ms:5.1f}% of conv time")
+        for e in sorted(shapes, key=lambda e: -e["ms"]):
+            log(f"[shape] {e['kernel']:<64s} n {e['launches']:5d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  "
+                f"{100 * e['ms'] / tot_ms:5.1f}%")
         dom = rep[0]
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = dom["flops"] / dom["ms"] / 1e9

@@ -99,6 +99,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.B = c.B; a.Hin = x0.H; a.Win = x0.W; a.Hout = Ho; a.Wout = Wo;
     a.Cin = Cin; a.Cout = w.cout;
     a.w = w.w; a.w_tap_stride = (long long)w.rows_pad * w.cin; a.w_img_stride = 0; a.w_row_stride = w.cin; a.w_rows = w.rows_pad;
+    a.w_bytes = (unsigned)((size_t)w.k * w.k * w.rows_pad * w.cin * dsize(c.dtype));
     a.bias = w.b; a.alpha = 1.0f;
     a.pro = scale ? 1 : 0; a.scale = scale; a.shift = shift;
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
@@ -179,6 +180,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
         a.B = c.B; a.Hin = a.Hout = x.H; a.Win = a.Wout = x.W;
         a.Cin = C; a.Cout = N;
         a.w = (const char*)qk.p + (size_t)C * es; a.w_tap_stride = 0; a.w_img_stride = (long long)N * 2 * C; a.w_row_stride = 2 * C; a.w_rows = N;
+        a.w_bytes = (unsigned)(((size_t)N * 2 * C - C) * es);     // this image's K rows (descriptor base moves per image)
         a.alpha = (float)std::pow((double)C, -0.5);
         a.y = S; a.y_mode = Y_NHWC_F32; a.y_s = N;
         WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
@@ -189,6 +191,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
         p.B = c.B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
         p.Cin = N; p.Cout = C;
         p.w = vT; p.w_tap_stride = 0; p.w_img_stride = (long long)C * N; p.w_row_stride = N; p.w_rows = C;
+        p.w_bytes = (unsigned)((size_t)C * N * es);
         p.alpha = 1.0f;
         p.y = o.p; p.y_mode = Y_NHWC; p.y_s = C;
         WDM_TRY(launch_conv(p, MODE_P1, c.dtype, c.s));

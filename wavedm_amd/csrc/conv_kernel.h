@@ -57,7 +57,8 @@ struct ConvArgs {
     const void* w;         // [tap][row][cin] (row = output channel), model dtype
     long long w_tap_stride, w_img_stride;  // elements; w_img_stride != 0: per-image weights (attention)
     int w_row_stride;      // elements
-    int w_rows;            // rows that exist in memory (rows >= w_rows read as zero)
+    int w_rows;            // informational: rows of the weight matrix (columns >= Cout are never stored)
+    unsigned x0_bytes, x1_bytes, w_bytes;   // extents for the buffer descriptors (reads past them return 0)
     const float* bias;     // [Cout] or nullptr
     float alpha;           // accumulator scale (attention: C^-0.5), 1 otherwise
     int pro;               // 0: none, 1: x*scale+shift then SiLU  (MODE_S1 only)
@@ -158,7 +159,7 @@ struct ConvCfg {
     static constexpr int B_IPT = (NSUB * BN * NU + NTHREADS - 1) / NTHREADS;      // B items per thread
     static constexpr bool PREFETCH = (MODE != MODE_S2);   // S2 tiles stage 4x the pixels: keep registers low
     // two workgroups per CU (one's LDS-fill phase overlaps the other's MFMA phase) need <= 256 registers per lane
-    static constexpr int MIN_WAVES = (LDS_BYTES <= 80 * 1024 && MODE != MODE_P1) ? 2 : 1;
+    static constexpr int MIN_WAVES = (LDS_BYTES <= 80 * 1024) ? 2 : 1;
     static_assert(M == 16 * WM * WAVES_M, "tile M mismatch");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(NI == 1 || (MODE == MODE_S1 || MODE == MODE_P1), "multi-image tiles: s1 / 1x1 only");
@@ -240,7 +241,6 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
     // ---- staging registers
     uint4 ra[NI][A_IPI];
     uint4 rb[B_IPT];
-    unsigned inb_mask = 0;                 // bit (img*A_IPI + i): item lies inside the image (transform applies)
     float sc[NI][VEC], sh[NI][VEC];
     static_assert(NI * A_IPI <= 32, "inb_mask too small");
 
@@ -248,38 +248,67 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
     const int nchunks = a.Cin / BK;                                   // slabs
     const int nstages = (MODE == MODE_P1) ? (nchunks + NSUB - 1) / NSUB : nchunks;
     const int wimg = (a.w_img_stride != 0) ? img0 : 0;
-    const T* wbase = (const T*)a.w + (long long)wimg * a.w_img_stride;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int RPI_ = C::NTHREADS / NU;                            // rows (pixels / weight rows) covered per item index
+
+    // ---- per-item geometry, computed ONCE.  All global traffic of the main loop goes through buffer loads whose
+    // per-lane byte offset (voffset) is loop-invariant; the channel-slab / tap advance is a wave-uniform SGPR
+    // offset.  Out-of-image halo pixels (and everything past the end of a tensor) carry an out-of-range voffset:
+    // the hardware bounds check returns zeros, so there are no branches and no address arithmetic in the loop.
+    constexpr unsigned OOB = 0xFFFF0000u;      // >= num_records of any tensor (host asserts tensors < 4 GB - 64 KB)
+    const __amdgpu_buffer_rsrc_t r_x0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, a.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x1 ? a.x1 : a.x0), 0, a.x1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.w + (long long)wimg * a.w_img_stride), 0,
+                                                                        a.w_bytes, 0x00020000);
+    unsigned a_v0[NI][A_IPI], a_v1[NI][A_IPI];   // byte offset of (pixel, unit) in x0 / x1
+    int a_l[NI][A_IPI];                          // LDS byte offset of the item (sub-plane included)
+    unsigned inb_mask = 0;                       // bit (img*A_IPI + i): item lies inside the image (transform applies)
+#pragma unroll
+    for (int im = 0; im < NI; ++im) {
+        const int img_g = img0 + im;
+#pragma unroll
+        for (int i = 0; i < A_IPI; ++i) {
+            const int pq = (tid >> 2) + i * RPI_;
+            const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
+            const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
+            const int hy = q / PW, hx = q - hy * PW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = (pq < NSUBA * NPIX) && (img_g < a.B) && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const unsigned gp = (unsigned)((img_g * a.Hin + iy) * a.Win + ix);
+            a_v0[im][i] = ok ? gp * (unsigned)(a.xs0 * ES) + (unsigned)(unit * 16) : OOB;
+            a_v1[im][i] = ok ? gp * (unsigned)(a.xs1 * ES) + (unsigned)(unit * 16) : OOB;
+            a_l[im][i] = sub * (PLANE * 64) + lds_off(im * PLANE_IMG + hy * RS + hx, unit);
+            if (ok) inb_mask |= 1u << (im * A_IPI + i);
+        }
+    }
+    // B items: row index rn = tid/4 + 64 i walks the [sub][n] rows of the stage linearly, so both the LDS offset and the
+    // global offset are (per-thread base) + (uniform function of i)
+    const int rb0 = tid >> 2;
+    const int b_l0 = A_BYTES + lds_off(rb0, unit);                    // + i * RPI_ * 64
+    unsigned b_v0;
+    if (BN >= RPI_) b_v0 = (unsigned)((n0 + rb0) * a.w_row_stride * ES + unit * 16);
+    else b_v0 = (unsigned)(((n0 + rb0 % BN) * (long long)a.w_row_stride + (rb0 / BN) * ((MODE == MODE_P1) ? (long long)BK : a.w_tap_stride)) * ES + unit * 16);
+
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) __attribute__((always_inline)) -> uint4 {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    };
 
     auto load_stage = [&](int st) __attribute__((always_inline)) {
         const int cbase = (MODE == MODE_P1) ? st * NSUB * BK : st * BK;
-        // ---- A items: thread -> (pixel = tid>>2 + 64 i, unit = tid&3): a quad of lanes reads one pixel's 64 bytes
+        // ---- A items (thread -> pixel tid/4 + 64 i, unit tid&3: a quad of lanes reads one pixel's 64 contiguous bytes)
 #pragma unroll
         for (int im = 0; im < NI; ++im) {
-            const int img_g = img0 + im;
 #pragma unroll
             for (int i = 0; i < A_IPI; ++i) {
-                const int pq = (tid >> 2) + i * (C::NTHREADS / NU);
-                const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
-                const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
-                const int hy = q / PW, hx = q - hy * PW;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const int c = cbase + sub * BK + unit * VEC;
-                bool ok = (pq < NSUBA * NPIX) && (img_g < a.B) && (c < a.Cin) &&
-                          (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) {
-                    const long long gp = ((long long)img_g * a.Hin + iy) * a.Win + ix;
-                    const T* src = (c < a.C0) ? (const T*)a.x0 + gp * a.xs0 + c : (const T*)a.x1 + gp * a.xs1 + (c - a.C0);
-                    v = *(const uint4*)src;
-                }
-                ra[im][i] = v;
-                const unsigned bit = 1u << (im * A_IPI + i);
-                inb_mask = ok ? (inb_mask | bit) : (inb_mask & ~bit);
+                // NPIX is a multiple of 64 for 1x1 tiles, so the slab of item i is a compile-time function of i
+                const int c = cbase + ((NSUBA == 1) ? 0 : (i * RPI_ / NPIX) * BK);       // wave-uniform
+                if (c < a.C0) ra[im][i] = load16(r_x0, a_v0[im][i], c * ES);
+                else ra[im][i] = load16(r_x1, a_v1[im][i], (c - a.C0) * ES);
             }
             if (MODE == MODE_S1) {
                 if (a.pro) {
                     const int c = cbase + unit * VEC;
-                    const int ig = img_g < a.B ? img_g : a.B - 1;
+                    const int ig = img0 + im < a.B ? img0 + im : a.B - 1;
                     const float* ps = a.scale + (long long)ig * a.Cin + c;
                     const float* pf = a.shift + (long long)ig * a.Cin + c;
 #pragma unroll
@@ -294,51 +323,53 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
         // ---- B items
 #pragma unroll
         for (int i = 0; i < B_IPT; ++i) {
-            const int rn = (tid >> 2) + i * (C::NTHREADS / NU);
-            const int sub = rn / BN, n = rn % BN;
-            const int c = (MODE == MODE_P1) ? cbase + sub * BK + unit * VEC : cbase + unit * VEC;
-            const int tap = (MODE == MODE_P1) ? 0 : sub;
-            const int row = n0 + n;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (sub < NSUB && c < a.Cin && row < a.w_rows)
-                v = *(const uint4*)(wbase + (long long)tap * a.w_tap_stride + (long long)row * a.w_row_stride + c);
-            rb[i] = v;
+            long long so;                                             // wave-uniform element offset of item i
+            if (BN >= RPI_) {
+                const int sub = (i * RPI_) / BN, nof = (i * RPI_) % BN;
+                so = (long long)nof * a.w_row_stride + ((MODE == MODE_P1) ? (long long)(cbase + sub * BK) : sub * a.w_tap_stride + cbase);
+            } else {
+                const int sub = i * (RPI_ / BN);
+                so = (MODE == MODE_P1) ? (long long)(cbase + sub * BK) : sub * a.w_tap_stride + cbase;
+            }
+            rb[i] = load16(r_w, b_v0, (int)(so * ES));
         }
     };
 
-    auto store_stage = [&]() __attribute__((always_inline)) {
-        const bool pro = (MODE == MODE_S1) && a.pro;
+    // GroupNorm-apply + SiLU on the prefetched A registers.  Runs right after the MFMAs of the previous stage were
+    // issued (VALU and matrix pipes overlap), so only the ds_writes sit between the two barriers.
+    auto transform_stage = [&]() __attribute__((always_inline)) {
+        if (MODE == MODE_S1) {
+            if (a.pro) {     // wave-uniform; out-of-image pixels stay zero (padding comes AFTER the activation)
 #pragma unroll
-        for (int im = 0; im < NI; ++im) {
+                for (int im = 0; im < NI; ++im) {
 #pragma unroll
-            for (int i = 0; i < A_IPI; ++i) {
-                const int pq = (tid >> 2) + i * (C::NTHREADS / NU);
-                constexpr int LIMIT = NSUBA * NPIX;
-                const bool may_overrun = (i + 1) * (C::NTHREADS / NU) > LIMIT;   // compile-time per unrolled i
-                if (!may_overrun || pq < LIMIT) {
-                    const int sub = (NSUBA == 1) ? 0 : pq / NPIX;
-                    const int q = (NSUBA == 1) ? pq : pq - sub * NPIX;
-                    const int hy = q / PW, hx = q - hy * PW;
-                    uint4 v = ra[im][i];
-                    if (pro) {       // wave-uniform; out-of-image pixels stay zero (padding comes AFTER the activation)
+                    for (int i = 0; i < A_IPI; ++i) {
                         float f[VEC];
-                        TI<T>::unpack(v, f);
+                        TI<T>::unpack(ra[im][i], f);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) f[e] = silu_f(f[e] * sc[im][e] + sh[im][e]);
                         const uint4 tv = TI<T>::pack(f);
                         const bool in = (inb_mask >> (im * A_IPI + i)) & 1u;
-                        v.x = in ? tv.x : 0u; v.y = in ? tv.y : 0u; v.z = in ? tv.z : 0u; v.w = in ? tv.w : 0u;
+                        ra[im][i] = make_uint4(in ? tv.x : 0u, in ? tv.y : 0u, in ? tv.z : 0u, in ? tv.w : 0u);
                     }
-                    *(uint4*)(smem + sub * (PLANE * 64) + lds_off(im * PLANE_IMG + hy * RS + hx, unit)) = v;
                 }
+            }
+        }
+    };
+
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int im = 0; im < NI; ++im) {
+#pragma unroll
+            for (int i = 0; i < A_IPI; ++i) {
+                const bool may_overrun = (i + 1) * RPI_ > NSUBA * NPIX;   // compile-time per unrolled i
+                if (!may_overrun || (tid >> 2) + i * RPI_ < NSUBA * NPIX) *(uint4*)(smem + a_l[im][i]) = ra[im][i];
             }
         }
 #pragma unroll
         for (int i = 0; i < B_IPT; ++i) {
-            const int rn = (tid >> 2) + i * (C::NTHREADS / NU);
-            const int sub = rn / BN, n = rn % BN;
-            const bool may_overrun = (i + 1) * (C::NTHREADS / NU) > NSUB * BN;
-            if (!may_overrun || sub < NSUB) *(uint4*)(smem + A_BYTES + sub * (BN * 64) + lds_off(n, unit)) = rb[i];
+            const bool may_overrun = (i + 1) * RPI_ > NSUB * BN;
+            if (!may_overrun || rb0 + i * RPI_ < NSUB * BN) *(uint4*)(smem + b_l0 + i * (RPI_ * 64)) = rb[i];
         }
     };
 
@@ -376,6 +407,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
     if (C::PREFETCH) load_stage(0);
     for (int st = 0; st < nstages; ++st) {
         if (!C::PREFETCH) load_stage(st);
+        transform_stage();
         __syncthreads();                  // everyone finished reading the previous stage
         store_stage();
         __syncthreads();
