@@ -1,0 +1,82 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header declares,
+the parameter table equals the reference's state_dict layout, host-side sampler arithmetic, fail-loud behaviour."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from wavedm_amd import _lib
+from wavedm_amd import procedural as P
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "wavedm.h")).read()
+    declared = sorted(set(re.findall(r"\b(wdm_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 24
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/wavedm.h but not exported"
+    assert sorted(_lib.EXPORTED) == declared
+    assert _lib.lib().wdm_abi_version() == 1
+
+
+@pytest.mark.parametrize("cfg", [P.raindrop_wavelet_config(), P.reduced_config(), P.raindrop_wavelet_config(image_size=128)])
+def test_param_table_matches_reference_state_dict_layout(cfg):
+    import wavedm_amd
+    net = wavedm_amd.DiffusionUNet(cfg, dtype="bf16")
+    sd = net.state_dict()
+    ref = P.unet_param_shapes(cfg)
+    assert set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    net.load_state_dict(P.procedural_state_dict(cfg) if cfg.model.ch == 32 else sd, strict=True)
+    assert net.module is net
+    assert net.packed_bytes() > sum(v.numel() for v in sd.values()) * 2 * 0.99
+    # workspace query is a pure host computation
+    assert int(_lib.lib().wdm_unet_workspace_bytes(net._u, 4)) > 0
+
+
+def test_no_cpu_fallback():
+    import wavedm_amd
+    with pytest.raises(TypeError):
+        wavedm_amd.WaveletTransform(scale=2, dec=True)(torch.zeros(1, 3, 8, 8))          # CPU tensor -> refuse
+    net = wavedm_amd.DiffusionUNet(P.reduced_config())
+    with pytest.raises((TypeError, RuntimeError)):
+        net(torch.zeros(1, 96, 16, 16), torch.zeros(1))
+    with pytest.raises(NotImplementedError):
+        wavedm_amd.WaveletTransform(scale=1, dec=True)
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    L = _lib.lib()
+    cfg = _lib.UNetConfig()
+    cfg.ch, cfg.n_levels, cfg.num_res_blocks, cfg.in_channels, cfg.out_ch, cfg.resolution = 30, 2, 2, 96, 3, 16
+    cfg.ch_mult[0], cfg.ch_mult[1], cfg.resamp_with_conv, cfg.dtype = 1, 2, 1, 1
+    u = C.c_void_p()
+    assert L.wdm_unet_create(None, C.byref(cfg), C.byref(u)) == -1                           # ch % 32 != 0
+    assert b"multiples of 32" in L.wdm_last_error()
+    cfg.ch, cfg.resolution = 32, 12
+    assert L.wdm_unet_create(None, C.byref(cfg), C.byref(u)) == -1                           # 12/2 = 6 not a multiple of 8
+    cfg.resolution = 16
+    assert L.wdm_unet_create(None, C.byref(cfg), C.byref(u)) == 0
+    assert L.wdm_unet_load_param(u, b"conv_in.weight", C.c_void_p(16), 1, None) == -4        # no packed buffer yet
+    assert L.wdm_unet_forward(u, C.c_void_p(16), C.c_void_p(16), 1, 1, C.c_void_p(16), C.c_void_p(256), 1 << 20, None) == -4
+    L.wdm_unet_destroy(u)
+
+
+def test_sampler_host_arithmetic_matches_oracle():
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import sampling
+    cfg = P.raindrop_wavelet_config()
+    b = torch.from_numpy(sampling.get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    assert torch.equal(b, O.beta_schedule(cfg))
+    tab = sampling.alpha_bar_table(b)
+    for t in (-1, 0, 10, 500, 990, 999):
+        assert float(tab[t + 1]) == float(O.compute_alpha(b, t))
+        assert float(sampling.compute_alpha(b, torch.tensor([t])).flatten()[0]) == float(O.compute_alpha(b, t))
+    for (h, w, p, r) in [(64, 64, 64, 16), (120, 180, 64, 16), (65, 70, 64, 16), (30, 45, 16, 4)]:
+        assert sampling.overlapping_grid_indices(h, w, p, r) == O.overlapping_grid_indices(h, w, p, r)
