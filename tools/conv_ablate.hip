@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "conv_kernel.h"
+#include "conv_ws_kernel.h"
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -23,27 +23,64 @@ int main(int argc, char** argv) {
     for (auto& v : hx) v = (unsigned short)(0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15));   // +-[0.5,1) bf16
     for (auto& v : hw) v = (unsigned short)(0x3c00 + (rand() & 0xff) + ((rand() & 1) << 15));
     CK(hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
-    std::vector<float> ones((size_t)B * Cin, 1.0f);
+    std::vector<float> ones((size_t)B * Cin, -1.4426950408889634f);
     CK(hipMemcpy(sc, ones.data(), ones.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(sh, 0, ones.size() * 4)); CK(hipMemset(bias, 0, Cout * 4));
     ConvArgs a{};
     a.x0 = x; a.C0 = Cin; a.xs0 = Cin; a.B = B; a.Hin = a.Win = a.Hout = a.Wout = H; a.Cin = Cin; a.Cout = Cout;
     a.w = w; a.w_tap_stride = (long long)Cout * Cin; a.w_row_stride = Cin; a.w_rows = Cout; a.bias = bias; a.alpha = 1.f;
     a.pro = pro; a.scale = sc; a.shift = sh; a.y = y; a.y_mode = Y_NHWC; a.y_s = Cout;
     a.x0_bytes = (unsigned)(nx * 2); a.w_bytes = (unsigned)(nw * 2);
+#if (WDM_ABL & 16)
+    unsigned long long* ts; CK(hipMalloc(&ts, 1 << 20)); CK(hipMemset(ts, 0, 1 << 20));
+    a.temb = (const float*)ts; a.temb_ld = 0; a.temb_per_image = 0;   // the instrumented kernel writes timestamps here
+#endif
+#ifdef WDM_WS
+    using C = ConvWsCfg<__bf16, 16, 16, 1, 4, 1, 4, 4>;
+    auto kern = conv_ws_kernel<__bf16, 16, 16, 1, 4, 1, 4, 4>;
+    const int nthr = C::NTHREADS;
+#elif defined(WDM_BN128)
+    using C = ConvCfg<__bf16, MODE_S1, 16, 16, 1, 4, 2, 4, 4>;
+    auto kern = conv_kernel<__bf16, MODE_S1, 16, 16, 1, 4, 2, 4, 4>;
+    const int nthr = 512;
+#else
     using C = ConvCfg<__bf16, MODE_S1, 16, 16, 1, 4, 1, 4, 4>;
-    a.mtiles = B * (H / 16) * (H / 16); a.ntiles = Cout / C::BN;
-    const int grid = ((a.mtiles + 7) / 8) * 8 * a.ntiles;
     auto kern = conv_kernel<__bf16, MODE_S1, 16, 16, 1, 4, 1, 4, 4>;
+    const int nthr = 256;
+#endif
+    a.mtiles = B * (H / 16) * (H / 16); a.ntiles = Cout / C::BN;
+    a.grid_gn = getenv("GN") ? atoi(getenv("GN")) : 1;
+    const int grid = 8 * ((a.ntiles + a.grid_gn - 1) / a.grid_gn) * ((a.mtiles + 8 / a.grid_gn - 1) / (8 / a.grid_gn));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), C::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     const int it = 20;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), C::LDS_BYTES, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * B * H * H * Cout * 9.0 * Cin;
-    printf("ABL=%d B=%d H=%d %d->%d pro=%d grid=%d lds=%d : %.1f us  %.1f TFLOP/s\n", WDM_ABL, B, H, Cin, Cout, pro, grid, C::LDS_BYTES, ms / it * 1e3, fl / (ms / it) / 1e9);
+    printf("%s gn=%d ABL=%d B=%d H=%d %d->%d pro=%d grid=%d lds=%d : %.1f us  %.1f TFLOP/s\n", nthr == 768 ? "WS" : nthr == 512 ? "BN128" : "  ", a.grid_gn, WDM_ABL, B, H, Cin, Cout, pro, grid, C::LDS_BYTES, ms / it * 1e3, fl / (ms / it) / 1e9);
+#if (WDM_ABL & 16)
+    {   // one instrumented launch; temb pointer is abused as the timestamp buffer (temb is added in the epilogue only when
+        // non-null, so run with a copy of the args whose epilogue ignores it: y_mode stays, temb_ld = 0 rows of zeros)
+        ConvArgs b = a; b.temb = (const float*)ts; b.temb_ld = 0; b.temb_per_image = 0;
+        CK(hipMemset(ts, 0, 8 * 12 * 8 * 8));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), C::LDS_BYTES, 0, b);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(8 * 12 * 8);
+        CK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+        const char* ph[6] = {"xform", "barA", "store", "barB", "loadissue", "compute"};
+        for (int blk = 0; blk < 2; ++blk) for (int w = 0; w < 4; ++w) {
+            printf("block%d wave%d:", blk ? 1000 : 0, w);
+            for (int st = 1; st < 6; ++st) {
+                const unsigned long long* t = &h[((blk * 4 + w) * 12 + st) * 8];
+                printf(" | st%d", st);
+                for (int k = 0; k < 6; ++k) printf(" %s=%llu", ph[k], t[k + 1] - t[k]);
+            }
+            printf("\n");
+        }
+    }
+#endif
     return 0;
 }

@@ -109,7 +109,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
 }
 
 // GroupNorm statistics of [x0 | x1] -> scale/shift (allocated here, caller frees both)
-static int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, float** scale, float** shift) {
+static int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift) {
     const int C = x0.C + (x1 ? x1->C : 0);
     const int HW = x0.H * x0.W;
     float* partial = nullptr;
@@ -117,7 +117,7 @@ static int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, float
     WDM_TRY(alloc_f32(c, (size_t)c.B * C, shift));
     WDM_TRY(alloc_f32(c, gn_partial_bytes(c.B, HW, C) / sizeof(float), &partial));
     int rc = WDM_OK;
-    if (!c.dry) rc = k_gn_scale_shift(x0, x1, c.B, nw, 1e-6f, partial, *scale, *shift, c.dtype, c.s);
+    if (!c.dry) rc = k_gn_scale_shift(x0, x1, c.B, nw, 1e-6f, for_silu_conv, partial, *scale, *shift, c.dtype, c.s);
     c.ar->free(partial);   // stream-ordered: later kernels that reuse this memory run after the finalize kernel
     return rc;
 }
@@ -129,10 +129,10 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
-    WDM_TRY(run_gn(c, w.n1, x0, x1, &sc1, &sh1));
+    WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
     WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr));
     c.ar->free(sc1); c.ar->free(sh1);
-    WDM_TRY(run_gn(c, w.n2, t1, nullptr, &sc2, &sh2));
+    WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
     const Tens* res = &x0;
     if (w.has_nin) {
         WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
@@ -154,7 +154,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     if (N % 64 || N > 512) WDM_FAIL(WDM_EINVAL, "attn: %d tokens unsupported (multiple of 64, <= 512)", N);
     const size_t es = dsize(c.dtype);
     float *sc, *sh;
-    WDM_TRY(run_gn(c, w.n, x, nullptr, &sc, &sh));
+    WDM_TRY(run_gn(c, w.n, x, nullptr, 0, &sc, &sh));
     Tens hn;
     WDM_TRY(alloc_tens(c, C, x.H, x.W, &hn));
     if (!c.dry) WDM_TRY(k_gn_apply(x, c.B, sc, sh, hn.p, c.dtype, c.s));

@@ -113,8 +113,9 @@ int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int 
 int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
 // GroupNorm(32, eps) statistics of the channel concat [x0 | x1] -> per-(image, channel) scale/shift
 size_t gn_partial_bytes(int B, int HW, int C);
-int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale,
-                     float* shift, int dtype, hipStream_t s);
+// for_silu_conv != 0: scale/shift are pre-multiplied by -log2(e) for the conv prologue (conv_kernel.h: gn_silu_unit)
+int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, int for_silu_conv, float* partial,
+                     float* scale, float* shift, int dtype, hipStream_t s);
 int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s);
 int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s);
 int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream_t s);

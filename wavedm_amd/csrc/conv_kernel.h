@@ -77,6 +77,7 @@ struct ConvArgs {
     int y_mode;            // Y_*
     int y_s;               // NHWC pixel stride of y in elements
     int mtiles, ntiles;
+    int grid_gn;           // XCD N-groups (1, 2, 4 or 8), see the kernel's tile mapping
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -105,13 +106,14 @@ template <> struct TI<__bf16> {
         f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
         f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
     }
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) {      // one v_cvt_pk_bf16_f32 (RNE)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+        const v2f v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
+    }
     __device__ static __forceinline__ uint4 pack(const float* f) {
-        uint4 u;
-        u.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
-        u.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
-        u.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
-        return u;
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
     __device__ static __forceinline__ float ld(const void* p, long long i) { return bf16_to_f32(((const bf16_raw*)p)[i]); }
     __device__ static __forceinline__ void st(void* p, long long i, float v) { ((bf16_raw*)p)[i] = f32_to_bf16(v); }
@@ -121,6 +123,29 @@ __device__ __forceinline__ float silu_f(float v) {
     // x * sigmoid(x) = x / (1 + e^-x)   (unet.py:31-33); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE divide:
     // this runs once per staged element in the conv prologue, where VALU issue slots compete with the MFMA stream
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+// GroupNorm-apply + SiLU on one 16-byte unit, written for the fewest issue slots (the SIMD's instruction issue, not a
+// pipe, bounds the conv kernel): scale/shift arrive pre-multiplied by -log2(e), so per PAIR of elements it is
+//   t = x*sc' + sh' (v_pk_fma)   e = 2^t (2 v_exp)   d = 1 + e (v_pk_add)   r = 1/d (2 v_rcp)
+//   v = t * (-ln 2) (v_pk_mul)   y = v * r (v_pk_mul)          =>  y = v * sigmoid(v),  v = x*scale + shift
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ uint4 gn_silu_unit(const uint4& u, const float* sc, const float* sh) {
+    constexpr int VEC = TI<T>::VEC;
+    float f[VEC];
+    TI<T>::unpack(u, f);
+#pragma unroll
+    for (int e = 0; e < VEC; e += 2) {
+        const f32x2 x = {f[e], f[e + 1]}, s2 = {sc[e], sc[e + 1]}, h2 = {sh[e], sh[e + 1]};
+        const f32x2 t = x * s2 + h2;
+        f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        d = d + 1.0f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        const f32x2 y = (t * -0.6931471805599453f) * r;
+        f[e] = y.x; f[e + 1] = y.y;
+    }
+    return TI<T>::pack(f);
 }
 
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
@@ -135,11 +160,121 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 }
 
 // ------------------------------------------------------------------------------------------------
+// epilogue: accumulators -> per-wave LDS tile (fp32) -> row-contiguous 16-byte global accesses.
+// The MFMA C layout gives a lane ONE channel of 4 pixels; storing from it directly costs one 2-byte store per
+// output (64 store instructions per lane, issue-bound).  Through LDS every lane owns 8 consecutive channels of
+// one pixel: alpha*acc + bias + temb + residual in fp32, then one 16-byte store (and one 16-byte residual load).
+// Every wave of the workgroup must call it (it contains workgroup barriers); waves with active == false (the
+// producer waves of the specialised kernel) only take part in the barriers.  `wave` indexes the LDS tile.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TH, int TW, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
+                                              int wave_n, int img0, int oy0, int ox0, int n0) {
+    constexpr int VEC = TI<T>::VEC;
+    constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
+    constexpr int ECOLS = 16 * NJ;
+    constexpr int ESTR = ECOLS + 4;                   // row stride (floats): 4*ESTR = 16 (mod 32) -> conflict-free writes
+    constexpr int EROWS = 16 * WM;
+    constexpr int LPR = ECOLS / 8;                    // lanes per row
+    constexpr int RPI = 64 / LPR;                     // rows per iteration
+    float* ep = (float*)smem + wave * (EROWS * ESTR);
+    const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += NJ) {
+        __syncthreads();                              // main loop / previous pass finished with this LDS
+        if (active)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
+        __syncthreads();
+        if (!active) continue;
+        const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
+        if (vec_ok) {
+            const int c8 = (lane % LPR) * 8;
+            const int n = ncol0 + c8;
+            float bias8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+#pragma unroll
+            for (int it = 0; it < EROWS / RPI; ++it) {
+                const int rloc = it * RPI + lane / LPR;
+                const int m = wave_m * EROWS + rloc;
+                const int img = m / (TH * TW), rr = m % (TH * TW);
+                const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
+                const int img_g = img0 + img;
+                if (n >= a.Cout || img_g >= a.B) continue;
+                const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
+                if (a.temb != nullptr) {
+                    const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
+                    const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
+                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                }
+                const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+                if (a.res != nullptr) {
+                    float rf[8];
+                    const T* rp = (const T*)a.res + opix * a.res_s + n;
+                    if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
+                    else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                }
+                if (a.y_mode == Y_NHWC) {
+                    T* yp = (T*)a.y + opix * a.y_s + n;
+                    if (VEC == 8) { *(uint4*)yp = TI<T>::pack(v); }
+                    else { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
+                } else {
+                    float* yp = (float*)a.y + opix * a.y_s + n;
+                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        } else {
+            // channel-major (NCHW) outputs and odd channel counts: lane = pixel row, loop over channels, so that
+            // for each channel the 64 lanes write runs of consecutive pixels
+#pragma unroll 1
+            for (int it = 0; it < (EROWS + 63) / 64; ++it) {
+                const int rloc = it * 64 + lane;
+                if (rloc >= EROWS) continue;
+                const int m = wave_m * EROWS + rloc;
+                const int img = m / (TH * TW), rr = m % (TH * TW);
+                const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
+                const int img_g = img0 + img;
+                if (img_g >= a.B) continue;
+                const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+#pragma unroll 4
+                for (int c = 0; c < ECOLS; ++c) {
+                    const int n = ncol0 + c;
+                    if (n >= a.Cout) break;
+                    float v = ep[rloc * ESTR + c] * a.alpha + (a.bias != nullptr ? a.bias[n] : 0.f);
+                    if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
+                    if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
+                    if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
+                    else if (a.y_mode == Y_NHWC_F32) ((float*)a.y)[opix * a.y_s + n] = v;
+                    else {
+                        const long long o = (((long long)img_g * a.Cout + n) * a.Hout + oy) * a.Wout + ox;
+                        if (a.y_mode == Y_NCHW) TI<T>::st(a.y, o, v);
+                        else ((float*)a.y)[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compile-time geometry of one kernel configuration
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, int KSUB = 4>
 struct ConvCfg {
-    static constexpr int NTHREADS = 256;
+    static constexpr int NWAVES = WAVES_M * WAVES_N;   // 4 (two workgroups per CU) or 8 (one workgroup per CU)
+    static constexpr int NTHREADS = 64 * NWAVES;
     static constexpr int VEC = TI<T>::VEC;
     static constexpr int NU = 4;                 // 16-byte k-units per slab
     static constexpr int BK = NU * VEC;          // channels per slab: 32 (bf16) / 16 (f32)
@@ -163,9 +298,9 @@ struct ConvCfg {
     static constexpr int B_IPT = (NSUB * BN * NU + NTHREADS - 1) / NTHREADS;      // B items per thread
     static constexpr bool PREFETCH = (MODE != MODE_S2);   // S2 tiles stage 4x the pixels: keep registers low
     // two workgroups per CU (one's LDS-fill phase overlaps the other's MFMA phase) need <= 256 registers per lane
-    static constexpr int MIN_WAVES = (LDS_BYTES <= 80 * 1024) ? 2 : 1;
+    static constexpr int MIN_WAVES = (NWAVES == 8 || LDS_BYTES <= 80 * 1024) ? 2 : 1;
     static_assert(M == 16 * WM * WAVES_M, "tile M mismatch");
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
     static_assert(NI == 1 || (MODE == MODE_S1 || MODE == MODE_P1), "multi-image tiles: s1 / 1x1 only");
 };
 
@@ -176,7 +311,8 @@ __device__ __forceinline__ int lds_off(int q, int u) { return (q << 6) | ((u ^ (
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, int KSUB = 4>
-__global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>::MIN_WAVES)) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>::NTHREADS),
+                             (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>::MIN_WAVES)) void conv_kernel(const ConvArgs a) {
     using C = ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN, KSUB>;
     constexpr int VEC = C::VEC, NU = C::NU, BK = C::BK, BN = C::BN;
     constexpr int NSUB = C::NSUB, NSUBA = C::NSUBA, PW = C::PW, RS = C::RS, NPIX = C::NPIX;
@@ -191,13 +327,26 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
-    // ---- workgroup -> (M tile, N tile).  Consecutive workgroups on one XCD (id % 8 is the XCD the dispatcher
-    // picks) walk the N tiles of the same M tile, so the A tile is re-read from that XCD's L2.
+    // ---- workgroup -> (M tile, N tile), XCD-aware (block id % 8 is the XCD the dispatcher picks; used for speed only).
+    // The 8 XCDs are split into gn N-groups x (8/gn) M-groups; XCD (xm, xn) owns the tiles mt = xm (mod gm), nt = xn (mod gn)
+    // and walks them M-fastest, so the ~64 workgroups resident on an XCD at any time share ONE (or few) weight tiles --
+    // which then stay in that XCD's 4 MB L2 -- while each A tile is streamed once per N tile of the XCD.  gn = 1 is the
+    // plain "N tiles of one M tile back to back" order used when the whole weight tensor fits in L2 anyway.
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, seq = bid >> 3;
-    const int nt = seq % a.ntiles;
-    const int mt = (seq / a.ntiles) * 8 + xcd;
-    if (mt >= a.mtiles) return;
+    int mt, nt;
+    {
+        const int gn = a.grid_gn, gm = 8 / gn;
+        const int xcd = bid & 7, seq = bid >> 3;
+        const int xn = xcd % gn, xm = xcd / gn;
+        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
+        if (gn == 1) {               // N fastest
+            if (seq >= mcnt * ncnt) return;
+            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
+        } else {                     // M fastest
+            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
+            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
+        }
+    }
     const int n0 = nt * BN;
 
     int img0, oy0, ox0;
@@ -297,20 +446,26 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
     };
 
-    auto load_stage = [&](int st) __attribute__((always_inline)) {
+    // Loads of stage st, restricted to the items k with k % nparts == part (nparts == 1: everything).
+    // (Spreading the next stage's loads over the nine tap groups of the current one was tried: the ~1300 cycles the
+    // wave spends issuing 15 KB of loads just move into the MFMA phase -- the vector-memory path, 64 B/clk/CU for
+    // 61 KB per stage, is the limit, not the position of the loads.  Phase timestamps: tools/conv_ablate.hip.)
+    auto load_part = [&](int st, int part, int nparts) __attribute__((always_inline)) {
         const int cbase = (MODE == MODE_P1) ? st * NSUB * BK : st * BK;
+        int k = 0;
         // ---- A items (thread -> pixel tid/4 + 64 i, unit tid&3: a quad of lanes reads one pixel's 64 contiguous bytes)
 #pragma unroll
         for (int im = 0; im < NI; ++im) {
 #pragma unroll
-            for (int i = 0; i < A_IPI; ++i) {
+            for (int i = 0; i < A_IPI; ++i, ++k) {
+                if (k % nparts != part) continue;
                 // NPIX is a multiple of 64 for 1x1 tiles, so the slab of item i is a compile-time function of i
                 const int c = cbase + ((NSUBA == 1) ? 0 : (i * RPI_ / NPIX) * BK);       // wave-uniform
                 if (c < a.C0) ra[im][i] = load16(r_x0, a_v0[im][i], c * ES);
                 else ra[im][i] = load16(r_x1, a_v1[im][i], (c - a.C0) * ES);
             }
             if (MODE == MODE_S1) {
-                if (a.pro) {
+                if (k++ % nparts == part && a.pro) {
                     const int c = cbase + unit * VEC;
                     const int ig = img0 + im < a.B ? img0 + im : a.B - 1;
                     const float* ps = a.scale + (long long)ig * a.Cin + c;
@@ -326,7 +481,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
         }
         // ---- B items
 #pragma unroll
-        for (int i = 0; i < B_IPT; ++i) {
+        for (int i = 0; i < B_IPT; ++i, ++k) {
+            if (k % nparts != part) continue;
             long long so;                                             // wave-uniform element offset of item i
             if (BN >= RPI_) {
                 const int sub = (i * RPI_) / BN, nof = (i * RPI_) % BN;
@@ -338,6 +494,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
             rb[i] = load16(r_w, b_v0, (int)(so * ES));
         }
     };
+    auto load_stage = [&](int st) __attribute__((always_inline)) { load_part(st, 0, 1); };
 
     // GroupNorm-apply + SiLU on the prefetched A registers.  Runs right after the MFMAs of the previous stage were
     // issued (VALU and matrix pipes overlap), so only the ds_writes sit between the two barriers.
@@ -348,11 +505,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
                 for (int im = 0; im < NI; ++im) {
 #pragma unroll
                     for (int i = 0; i < A_IPI; ++i) {
-                        float f[VEC];
-                        TI<T>::unpack(ra[im][i], f);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) f[e] = silu_f(f[e] * sc[im][e] + sh[im][e]);
-                        const uint4 tv = TI<T>::pack(f);
+                        const uint4 tv = gn_silu_unit<T>(ra[im][i], sc[im], sh[im]);
                         const bool in = (inb_mask >> (im * A_IPI + i)) & 1u;
                         ra[im][i] = make_uint4(in ? tv.x : 0u, in ? tv.y : 0u, in ? tv.z : 0u, in ? tv.w : 0u);
                     }
@@ -435,117 +588,37 @@ __global__ __launch_bounds__(256, (ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N
     };
 
     // ---- main loop
+#if (WDM_ABL & 16)
+    // phase timestamps (ablation builds only): block 0 and a middle block, every wave, first 12 stages
+    unsigned long long* tsbuf = (unsigned long long*)a.temb;
+    const bool ts_on = (bid == 0 || bid == 1000) && lane == 0;
+    const int ts_base = ((bid == 0 ? 0 : 1) * 4 + wave) * 12 * 8;
+#define WDM_TS(ph) do { if (ts_on && st < 12) tsbuf[ts_base + st * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WDM_TS(ph) do { } while (0)
+#endif
     if (C::PREFETCH) load_stage(0);
     for (int st = 0; st < nstages; ++st) {
         if (!C::PREFETCH) load_stage(st);
+        WDM_TS(0);
         transform_stage();
+        WDM_TS(1);
         __syncthreads();                  // everyone finished reading the previous stage
+        WDM_TS(2);
         if (!(WDM_ABL & 4) || st == 0) store_stage();
+        WDM_TS(3);
         __syncthreads();
+        WDM_TS(4);
         if (C::PREFETCH && st + 1 < nstages && !(WDM_ABL & 2)) load_stage(st + 1);
+        WDM_TS(5);
         compute_stage(st);
+        WDM_TS(6);
     }
+#undef WDM_TS
 
-    // ---- epilogue: accumulators -> per-wave LDS tile (fp32) -> row-contiguous 16-byte global accesses.
-    // The MFMA C layout gives a lane ONE channel of 4 pixels; storing from it directly costs one 2-byte store per
-    // output (64 store instructions per lane, issue-bound).  Through LDS every lane owns 8 consecutive channels of
-    // one pixel: alpha*acc + bias + temb + residual in fp32, then one 16-byte store (and one 16-byte residual load).
-    {
-        constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
-        constexpr int ECOLS = 16 * NJ;
-        constexpr int ESTR = ECOLS + 4;                   // row stride (floats): 4*ESTR = 16 (mod 32) -> conflict-free writes
-        constexpr int EROWS = 16 * WM;
-        constexpr int LPR = ECOLS / 8;                    // lanes per row
-        constexpr int RPI = 64 / LPR;                     // rows per iteration
-        static_assert(4 * EROWS * ESTR * 4 <= C::LDS_BYTES, "epilogue tile does not fit in LDS");
-        float* ep = (float*)smem + wave * (EROWS * ESTR);
-        const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
-#pragma unroll
-        for (int jp = 0; jp < WN; jp += NJ) {
-            __syncthreads();                              // main loop / previous pass finished with this LDS
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
-            __syncthreads();
-            const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
-            if (vec_ok) {
-                const int c8 = (lane % LPR) * 8;
-                const int n = ncol0 + c8;
-                float bias8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bias8[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
-#pragma unroll
-                for (int it = 0; it < EROWS / RPI; ++it) {
-                    const int rloc = it * RPI + lane / LPR;
-                    const int m = wave_m * EROWS + rloc;
-                    const int img = m / (TH * TW), rr = m % (TH * TW);
-                    const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
-                    const int img_g = img0 + img;
-                    if (n >= a.Cout || img_g >= a.B) continue;
-                    const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
-                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
-                    if (a.temb != nullptr) {
-                        const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
-                        const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
-                        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
-                    }
-                    const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
-                    if (a.res != nullptr) {
-                        float rf[8];
-                        const T* rp = (const T*)a.res + opix * a.res_s + n;
-                        if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
-                        else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-                    }
-                    if (a.y_mode == Y_NHWC) {
-                        T* yp = (T*)a.y + opix * a.y_s + n;
-                        if (VEC == 8) { *(uint4*)yp = TI<T>::pack(v); }
-                        else { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
-                    } else {
-                        float* yp = (float*)a.y + opix * a.y_s + n;
-                        *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-                        *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                }
-            } else {
-                // channel-major (NCHW) outputs and odd channel counts: lane = pixel row, loop over channels, so that
-                // for each channel the 64 lanes write runs of consecutive pixels
-#pragma unroll 1
-                for (int it = 0; it < (EROWS + 63) / 64; ++it) {
-                    const int rloc = it * 64 + lane;
-                    if (rloc >= EROWS) continue;
-                    const int m = wave_m * EROWS + rloc;
-                    const int img = m / (TH * TW), rr = m % (TH * TW);
-                    const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
-                    const int img_g = img0 + img;
-                    if (img_g >= a.B) continue;
-                    const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
-#pragma unroll 4
-                    for (int c = 0; c < ECOLS; ++c) {
-                        const int n = ncol0 + c;
-                        if (n >= a.Cout) break;
-                        float v = ep[rloc * ESTR + c] * a.alpha + (a.bias != nullptr ? a.bias[n] : 0.f);
-                        if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
-                        if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
-                        if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
-                        else if (a.y_mode == Y_NHWC_F32) ((float*)a.y)[opix * a.y_s + n] = v;
-                        else {
-                            const long long o = (((long long)img_g * a.Cout + n) * a.Hout + oy) * a.Wout + ox;
-                            if (a.y_mode == Y_NCHW) TI<T>::st(a.y, o, v);
-                            else ((float*)a.y)[o] = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue
+    static_assert(C::NWAVES * 16 * WM * (16 * (WN >= 2 ? 2 : 1) + 4) * 4 <= C::LDS_BYTES, "epilogue tile does not fit in LDS");
+    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0);
 }
 
 // host-side launchers implemented per dtype in conv_bf16.hip / conv_f32.hip

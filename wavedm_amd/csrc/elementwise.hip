@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
                                                          int nslab, const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                                         const float* __restrict__ beta, float eps, float premul, float* __restrict__ scale,
+                                                         float* __restrict__ shift) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int gw = C / 32;
     const int lane = threadIdx.x;
@@ -306,13 +307,14 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const T* __restrict__ x
     for (int ci = lane; ci < gw; ci += 64) {
         const int c = g * gw + ci;
         const float sc = rstd * gamma[c];
-        scale[(long long)b * C + c] = sc;
-        shift[(long long)b * C + c] = beta[c] - mean * sc;
+        scale[(long long)b * C + c] = sc * premul;
+        shift[(long long)b * C + c] = (beta[c] - mean * sc) * premul;
     }
 }
 
 template <typename T>
-static int gn_launch(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale, float* shift, hipStream_t s) {
+static int gn_launch(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float premul, float* partial, float* scale, float* shift,
+                     hipStream_t s) {
     constexpr int VEC = TI<T>::VEC;
     const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1;
     const int HW = x0.H * x0.W;
@@ -328,14 +330,17 @@ static int gn_launch(const Tens& x0, const Tens* x1, int B, const NormW& nw, flo
         hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x1->p, x1->xs, C1, HW, nslab, C0, C, partial);
     }
     hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(32, B), dim3(64), 0, s, (const T*)x0.p, x0.xs, C0, x1 ? (const T*)x1->p : (const T*)x0.p, x1 ? x1->xs : 0, C,
-                       HW, nslab, partial, nw.g, nw.b, eps, scale, shift);
+                       HW, nslab, partial, nw.g, nw.b, eps, premul, scale, shift);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
 
-int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float* partial, float* scale, float* shift, int dtype,
-                     hipStream_t s) {
-    return dtype == WDM_BF16 ? gn_launch<__bf16>(x0, x1, B, nw, eps, partial, scale, shift, s) : gn_launch<float>(x0, x1, B, nw, eps, partial, scale, shift, s);
+int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, int for_silu_conv, float* partial, float* scale, float* shift,
+                     int dtype, hipStream_t s) {
+    // for_silu_conv: the consumer is a conv with the fused GN+SiLU prologue, which wants scale/shift pre-multiplied by -log2(e)
+    const float premul = for_silu_conv ? -1.4426950408889634f : 1.0f;
+    return dtype == WDM_BF16 ? gn_launch<__bf16>(x0, x1, B, nw, eps, premul, partial, scale, shift, s)
+                             : gn_launch<float>(x0, x1, B, nw, eps, premul, partial, scale, shift, s);
 }
 
 // GroupNorm apply without activation (AttnBlock.norm, unet.py:169-170): y = x*scale + shift, NHWC dense output

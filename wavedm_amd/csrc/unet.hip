@@ -279,7 +279,7 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         WDM_TRY(af((size_t)c.B * h.C, &sc));
         WDM_TRY(af((size_t)c.B * h.C, &sh));
         WDM_TRY(af(gn_partial_bytes(c.B, h.H * h.W, h.C) / 4, &partial));
-        if (!c.dry) WDM_TRY(k_gn_scale_shift(h, nullptr, c.B, nw(norm_out), 1e-6f, partial, sc, sh, c.dtype, c.s));
+        if (!c.dry) WDM_TRY(k_gn_scale_shift(h, nullptr, c.B, nw(norm_out), 1e-6f, 1, partial, sc, sh, c.dtype, c.s));
         c.ar->free(partial);
         Tens dummy;
         WDM_TRY(run_conv(c, cw(conv_out), MODE_S1, h, nullptr, sc, sh, nullptr, 0, 0, nullptr, &dummy, Y_NCHW_F32, eps_out));
