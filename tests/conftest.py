@@ -10,6 +10,18 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def _limit_cpu_threads():
+    # the CPU oracle (oneDNN) is several times slower with 128+ threads than with 16 on the GPU box's 256-thread host
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
+
+
+_limit_cpu_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

@@ -134,3 +134,57 @@ def test_full_size_properties_bf16():
     assert torch.equal(a, b) and torch.isfinite(a).all()
     c = net(x[17:25].contiguous(), t)
     assert torch.equal(a[17:25], c)
+
+
+def test_config2_r128_forward():
+    """BASELINE.json configs[2] geometry: 128x128 wavelet-domain patches (attention moves to the 768-channel level,
+    N = 256 tokens, d = 768; 163.05 M params).  One forward of 2 patches vs the CPU oracle, both dtypes."""
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import procedural as P
+    cfg = P.raindrop_wavelet_config(image_size=128)
+    sd = P.procedural_state_dict(cfg)
+    assert sum(v.numel() for v in sd.values()) == 163053955                     # BASELINE.md §2
+    x = seeded((2, 96, 128, 128), 7)
+    t = torch.tensor([470.0])
+    want = O.unet_forward(sd, cfg, x, t)
+    for dtype in ("f32", "bf16"):
+        import wavedm_amd
+        net = wavedm_amd.DiffusionUNet(cfg, dtype=dtype)
+        net.load_state_dict(sd, strict=True)
+        got = net.cuda()(x.cuda(), t).cpu()
+        e = rel_linf(got, want)
+        print(f"config2 R=128 {dtype}: rel_linf {e:.3e}")
+        assert e <= TOL[dtype]
+        del net
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config4_fullres_stitch(dtype):
+    """BASELINE.json configs[4] geometry: one 480x720 image -> 120x180 wavelet domain -> 45 overlapping 64x64 patches
+    (r = 16) through the full-width UNet, DiffusiveRestoration.restore end to end, 5 DDIM steps, vs the CPU oracle."""
+    import wavedm_amd
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import procedural as P
+    cfg = P.raindrop_wavelet_config()
+    sd = P.procedural_state_dict(cfg)
+    d, args = make_diffusion(cfg, dtype, 5)
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(1, 3, 480, 720, generator=g)
+    gt = torch.rand(1, 3, 480, 720, generator=g)
+    x_T = torch.randn(1, 3, 120, 180, generator=g)
+    rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
+    real_randn = torch.randn
+    x_T_dev = x_T.cuda()
+    torch.randn = lambda *a, **k: x_T_dev.clone()
+    try:
+        outs, _ = rest.restore([(torch.cat([img, gt], 1), "full0", torch.zeros(1))], validation="raindrop", r=16)
+    finally:
+        torch.randn = real_randn
+    assert outs[0].shape == (1, 3, 480, 720)
+    want, xs, x0 = O.restore(sd, cfg, img, x_T, 5, r=16)
+    assert len(O.grid_corners(120, 180, 64, 16)) == 45
+    if dtype == "f32":
+        assert rel_linf(outs[0].cpu(), want) <= 1e-3
+    else:
+        assert float((outs[0].cpu() - want).abs().mean()) <= 2e-2

@@ -63,7 +63,11 @@ int alloc_tens(Ctx& c, int C, int H, int W, Tens* t) {
     if (!t->p) WDM_FAIL(WDM_ENOMEM, "workspace too small (tensor %dx%dx%dx%d)", c.B, H, W, C);
     return WDM_OK;
 }
-void free_tens(Ctx& c, Tens& t) { c.ar->free(t.p); t.p = nullptr; }
+void free_tens(Ctx& c, Tens& t) {
+    c.ar->free(t.p);
+    if (t.stats) c.ar->free(t.stats);
+    t.p = nullptr; t.stats = nullptr; t.nslab = 0;
+}
 
 static int alloc_f32(Ctx& c, size_t n, float** p) {
     *p = (float*)c.ar->alloc(n * sizeof(float));
@@ -78,7 +82,7 @@ int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
 // ---- one fused convolution ---------------------------------------------------------------------
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
-             int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext) {
+             int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -91,7 +95,6 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         y = out->p;
         y_mode = Y_NHWC;
     }
-    if (c.dry) return WDM_OK;
     ConvArgs a{};
     a.x0 = x0.p; a.x1 = x1 ? x1->p : nullptr;
     a.C0 = x0.C; a.C1 = x1 ? x1->C : 0;
@@ -105,20 +108,44 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
     a.res = res ? res->p : nullptr; a.res_s = res ? res->xs : 0;
     a.y = y; a.y_mode = y_mode; a.y_s = w.cout;
+    if (want_stats && !y_ext && w.cout % 8 == 0) {
+        // the producing conv also emits the GroupNorm partial statistics of its output (no extra pass over HBM)
+        int nslab = 0;
+        ConvArgs q = a;
+        q.query_nslab = &nslab;
+        WDM_TRY(launch_conv(q, mode, c.dtype, c.s));
+        out->nslab = nslab;
+        out->stats = (float*)c.ar->alloc(gn_stats_bytes(c.B, nslab, w.cout));
+        if (!out->stats) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
+        a.stats = out->stats; a.stats_nslab = nslab;
+    }
+    if (c.dry) return WDM_OK;
     return launch_conv(a, mode, c.dtype, c.s);
 }
 
-// GroupNorm statistics of [x0 | x1] -> scale/shift (allocated here, caller frees both)
-static int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift) {
+// GroupNorm statistics of [x0 | x1] -> scale/shift (allocated here, caller frees both).  Tensors that came out of a conv
+// carry their partial statistics already (Tens::stats); for the others a partial pass over the tensor runs first.
+int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift) {
     const int C = x0.C + (x1 ? x1->C : 0);
     const int HW = x0.H * x0.W;
-    float* partial = nullptr;
     WDM_TRY(alloc_f32(c, (size_t)c.B * C, scale));
     WDM_TRY(alloc_f32(c, (size_t)c.B * C, shift));
-    WDM_TRY(alloc_f32(c, gn_partial_bytes(c.B, HW, C) / sizeof(float), &partial));
+    const Tens* src[2] = {&x0, x1};
+    float* st[2] = {nullptr, nullptr};
+    float* tmp[2] = {nullptr, nullptr};
+    int ns[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        if (!src[k]) continue;
+        if (src[k]->stats) { st[k] = src[k]->stats; ns[k] = src[k]->nslab; continue; }
+        ns[k] = gn_default_nslab(HW);
+        tmp[k] = (float*)c.ar->alloc(gn_stats_bytes(c.B, ns[k], src[k]->C));
+        if (!tmp[k]) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
+        st[k] = tmp[k];
+        if (!c.dry) WDM_TRY(k_gn_partial(*src[k], c.B, tmp[k], ns[k], c.dtype, c.s));
+    }
     int rc = WDM_OK;
-    if (!c.dry) rc = k_gn_scale_shift(x0, x1, c.B, nw, 1e-6f, for_silu_conv, partial, *scale, *shift, c.dtype, c.s);
-    c.ar->free(partial);   // stream-ordered: later kernels that reuse this memory run after the finalize kernel
+    if (!c.dry) rc = k_gn_finalize(c.B, HW, st[0], ns[0], x0.C, st[1], ns[1], x1 ? x1->C : 0, nw, 1e-6f, for_silu_conv, *scale, *shift, c.s);
+    for (int k = 0; k < 2; ++k) if (tmp[k]) c.ar->free(tmp[k]);    // stream-ordered reuse
     return rc;
 }
 
@@ -130,7 +157,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
     WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
-    WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr));
+    WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
     c.ar->free(sc1); c.ar->free(sh1);
     WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
     const Tens* res = &x0;
@@ -138,7 +165,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
         res = &sct;
     }
-    WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr));
+    WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
     c.ar->free(sc2); c.ar->free(sh2);
     free_tens(c, t1);
     if (w.has_nin) free_tens(c, sct);
@@ -198,7 +225,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     }
     c.ar->free(S); c.ar->free(P); c.ar->free(vT);
     free_tens(c, qk);
-    WDM_TRY(run_conv(c, w.proj, MODE_P1, o, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr));
+    WDM_TRY(run_conv(c, w.proj, MODE_P1, o, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true));
     free_tens(c, o);
     return WDM_OK;
 }

@@ -60,6 +60,8 @@ struct Tens {
     void* p = nullptr;
     int C = 0, H = 0, W = 0;
     int xs = 0;   // pixel stride in elements
+    float* stats = nullptr;   // GroupNorm partial statistics float4[B][nslab][C] written by the producing conv, or nullptr
+    int nslab = 0;
 };
 
 struct Ctx {
@@ -111,11 +113,14 @@ int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const 
                   float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s);
 int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
 int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
-// GroupNorm(32, eps) statistics of the channel concat [x0 | x1] -> per-(image, channel) scale/shift
-size_t gn_partial_bytes(int B, int HW, int C);
+// GroupNorm(32, eps): partial statistics float4[B][nslab][C] = (pivot, sum(x-K), sum((x-K)^2), n) and their finalisation
+// over the channel concat of up to two tensors -> per-(image, channel) scale/shift.
 // for_silu_conv != 0: scale/shift are pre-multiplied by -log2(e) for the conv prologue (conv_kernel.h: gn_silu_unit)
-int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, int for_silu_conv, float* partial,
-                     float* scale, float* shift, int dtype, hipStream_t s);
+int gn_default_nslab(int HW);
+size_t gn_stats_bytes(int B, int nslab, int C);
+int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s);
+int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw,
+                  float eps, int for_silu_conv, float* scale, float* shift, hipStream_t s);
 int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s);
 int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s);
 int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream_t s);
@@ -136,8 +141,11 @@ void prof_end(hipStream_t s);
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 
 // ---- blocks (blocks.hip) ----------------------------------------------------------------------
+// want_stats: also emit the GroupNorm partial statistics of the output (out->stats) from the conv epilogue
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
-             const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext);
+             const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
+             bool want_stats = false);
+int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
 int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);
 int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);

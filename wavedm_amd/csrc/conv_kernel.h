@@ -78,6 +78,9 @@ struct ConvArgs {
     int y_s;               // NHWC pixel stride of y in elements
     int mtiles, ntiles;
     int grid_gn;           // XCD N-groups (1, 2, 4 or 8), see the kernel's tile mapping
+    float* stats;          // optional: GroupNorm partial statistics of the output, float4[B][stats_nslab][Cout] (see elementwise.hip)
+    int stats_nslab;       // slabs per image = tiles per image x wave tiles (in M) per tile
+    int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -167,9 +170,14 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 // Every wave of the workgroup must call it (it contains workgroup barriers); waves with active == false (the
 // producer waves of the specialised kernel) only take part in the barriers.  `wave` indexes the LDS tile.
 // ------------------------------------------------------------------------------------------------
+// Rows per GroupNorm-statistics slab.  It depends on the pixel tile only -- not on how many images a workgroup covers --
+// so the partial sums (hence scale/shift, hence every output bit) are the same whatever batch an image sits in:
+// 8x8 tiles always use half-image slabs (32 rows) whether one or two images share a workgroup.
+__host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { return (TH * TW == 64) ? (EROWS < 32 ? EROWS : 32) : EROWS; }
+
 template <typename T, int TH, int TW, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
-                                              int wave_n, int img0, int oy0, int ox0, int n0) {
+                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img) {
     constexpr int VEC = TI<T>::VEC;
     constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
     constexpr int ECOLS = 16 * NJ;
@@ -199,6 +207,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
             float bias8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bias8[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+            // GroupNorm partial statistics of the values as stored (optional): the final values go back into the LDS tile
+            // and a column pass (lane = channel) sums them -- no cross-lane shuffles
+            const bool do_stats = a.stats != nullptr;
 #pragma unroll
             for (int it = 0; it < EROWS / RPI; ++it) {
                 const int rloc = it * RPI + lane / LPR;
@@ -206,34 +217,86 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 const int img = m / (TH * TW), rr = m % (TH * TW);
                 const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
                 const int img_g = img0 + img;
-                if (n >= a.Cout || img_g >= a.B) continue;
+                const bool valid = n < a.Cout && img_g < a.B;
+                if (!valid && !do_stats) continue;
                 const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
-                if (a.temb != nullptr) {
-                    const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
-                    const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
-                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
-                }
-                const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
-                if (a.res != nullptr) {
-                    float rf[8];
-                    const T* rp = (const T*)a.res + opix * a.res_s + n;
-                    if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
-                    else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
+                const long long opix = ((long long)(valid ? img_g : 0) * a.Hout + oy) * a.Wout + ox;
+                if (valid) {
+                    if (a.temb != nullptr) {
+                        const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
+                        const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
+                        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                    }
+                    if (a.res != nullptr) {
+                        float rf[8];
+                        const T* rp = (const T*)a.res + opix * a.res_s + n;
+                        if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
+                        else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                    }
                 }
+                float vr[8];                                   // the values as the consumer will read them back
                 if (a.y_mode == Y_NHWC) {
                     T* yp = (T*)a.y + opix * a.y_s + n;
-                    if (VEC == 8) { *(uint4*)yp = TI<T>::pack(v); }
-                    else { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
+                    if (VEC == 8) { const uint4 pk = TI<T>::pack(v); TI<T>::unpack(pk, vr); if (valid) *(uint4*)yp = pk; }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vr[e] = v[e];
+                        if (valid) { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
+                    }
                 } else {
-                    float* yp = (float*)a.y + opix * a.y_s + n;
-                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-                    *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vr[e] = v[e];
+                    if (valid) {
+                        float* yp = (float*)a.y + opix * a.y_s + n;
+                        *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                 }
+                if (do_stats) {
+                    *(float4*)(ep + rloc * ESTR + c8) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+                    *(float4*)(ep + rloc * ESTR + c8 + 4) = make_float4(vr[4], vr[5], vr[6], vr[7]);
+                }
+            }
+            if (do_stats) {
+                // wave-local: the LDS executes one wave's instructions in order, so the column reads below see the
+                // write-backs above; the fence only stops the compiler from reordering them
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                constexpr int SROWS = conv_stat_rows(TH, TW, EROWS);     // rows per statistics slab
+                constexpr int PARTS = 64 / ECOLS;                         // lane groups splitting the rows
+                constexpr int RPP = EROWS / PARTS;                        // rows per lane
+                static_assert(SROWS % RPP == 0 && EROWS % SROWS == 0, "statistics slab geometry");
+                const int col = lane % ECOLS, part = lane / ECOLS;
+                const int r0 = part * RPP;
+                const int srow = (r0 / SROWS) * SROWS;                    // first row of this lane's slab
+                const float K = ep[srow * ESTR + col];
+                // fixed association: 16-row chunks summed in row order, chunks added in ascending order, then lane groups --
+                // identical whether a slab's 32 rows sit in one lane (two images per workgroup) or in two (one image)
+                float s1 = 0.f, s2 = 0.f;
+                constexpr int CH = RPP < 16 ? RPP : 16;
+                static_assert(RPP % CH == 0, "statistics rows per lane must be a multiple of the chunk");
+#pragma unroll
+                for (int ch = 0; ch < RPP / CH; ++ch) {
+                    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) { const float d = ep[(r0 + ch * CH + r) * ESTR + col] - K; c1 += d; c2 += d * d; }
+                    if (ch == 0) { s1 = c1; s2 = c2; } else { s1 += c1; s2 += c2; }
+                }
+#pragma unroll
+                for (int off = ECOLS; off < ECOLS * (SROWS / RPP); off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                // all rows of a wave tile belong to one image
+                const int m0 = wave_m * EROWS + srow;
+                const int img_g = img0 + m0 / (TH * TW);
+                constexpr int SPT = (TH * TW) / SROWS;                    // slabs per tile per image
+                const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS;
+                const int nn = ncol0 + col;
+                if ((r0 % SROWS) == 0 && nn < a.Cout && img_g < a.B)
+                    ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, (float)SROWS);
             }
         } else {
             // channel-major (NCHW) outputs and odd channel counts: lane = pixel row, loop over channels, so that
@@ -349,12 +412,13 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
     }
     const int n0 = nt * BN;
 
-    int img0, oy0, ox0;
+    int img0, oy0, ox0, tile_in_img = 0;
     if (NI == 1) {
         const int twn = a.Wout / TW;
         const int tpi = (a.Hout / TH) * twn;
         img0 = mt / tpi;
         const int t = mt - img0 * tpi;
+        tile_in_img = t;
         oy0 = (t / twn) * TH;
         ox0 = (t % twn) * TW;
     } else {
@@ -618,7 +682,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 
     // ---- epilogue
     static_assert(C::NWAVES * 16 * WM * (16 * (WN >= 2 ? 2 : 1) + 4) * 4 <= C::LDS_BYTES, "epilogue tile does not fit in LDS");
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0);
+    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 // host-side launchers implemented per dtype in conv_bf16.hip / conv_f32.hip

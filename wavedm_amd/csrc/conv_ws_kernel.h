@@ -80,12 +80,13 @@ __global__ __launch_bounds__((ConvWsCfg<T, TH, TW, NI, WAVES_M, WAVES_N, WM, WN,
         else { mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt); }
     }
     const int n0 = nt * BN;
-    int img0, oy0, ox0;
+    int img0, oy0, ox0, tile_in_img = 0;
     if (NI == 1) {
         const int twn = a.Wout / TW;
         const int tpi = (a.Hout / TH) * twn;
         img0 = mt / tpi;
         const int t = mt - img0 * tpi;
+        tile_in_img = t;
         oy0 = (t / twn) * TH;
         ox0 = (t % twn) * TW;
     } else {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__((ConvWsCfg<T, TH, TW, NI, WAVES_M, WAVES_N, WM, WN,
     }
 
     static_assert(4 * 16 * WM * (16 * (WN >= 2 ? 2 : 1) + 4) * 4 <= C::LDS_BYTES, "epilogue tile does not fit in LDS");
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, !is_prod, cw, lane, wave_m, wave_n, img0, oy0, ox0, n0);
+    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, !is_prod, cw, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm

@@ -212,21 +212,23 @@ int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int 
 // =================================================================================================
 // GroupNorm(32 groups, eps, biased variance) statistics -> per-(image, channel) scale / shift   (unet.py:36-37)
 //
-// Pass 1 (gn_partial_kernel): one workgroup per (pixel slab, image) streams the NHWC tensor with 16-byte loads;
-// each thread owns a fixed 16-byte channel vector and accumulates sum(x-K) and sum((x-K)^2) with the per-channel
-// pivot K = x[b, pixel 0, c] (shifted-data variance: no catastrophic cancellation), rows are reduced through LDS in
-// fixed order.  Pass 2 (gn_finalize_kernel): one wave per (image, group) re-centres the per-channel partials on a
-// common pivot and reduces them in fp64 with a fixed shuffle tree, then writes
-//     scale[b,c] = rstd*gamma[c],  shift[b,c] = beta[c] - mean*scale[b,c]
-// which the consuming conv applies while staging its A operand.  Two input tensors = the channel concat [x0 | x1];
-// groups may straddle the seam (1280 = 768 + 512 channels -> 40-channel groups).
+// Partial statistics live in a "stats" buffer float4[B][nslab][C] = (K, S1, S2, n): over the n pixels of a slab,
+// S1 = sum(x-K), S2 = sum((x-K)^2) with a per-(slab, channel) pivot K taken from the data (shifted-data variance: no
+// catastrophic cancellation).  They are produced either
+//   * by the epilogue of the convolution that writes the tensor (conv_kernel.h: the values are in registers anyway;
+//     one slab = the rows of one wave's output tile) -- the normal case inside the UNet, no extra pass over HBM; or
+//   * by gn_partial_kernel (one workgroup per (pixel slab, image), 16-byte loads, fixed-order LDS reduction) for
+//     tensors that did not come out of a conv (block-level entry points, the tests).
+// gn_finalize_kernel: one wave per (image, group) re-centres the partials of the group's channels -- which may come
+// from TWO tensors, the channel concat [x0 | x1] (1280 = 768 + 512 channels -> 40-channel groups straddle the seam) --
+// on a common pivot, reduces them in fp64 with a fixed shuffle tree and writes
+//     scale[b,c] = rstd*gamma[c],  shift[b,c] = beta[c] - mean*scale[b,c]      (times -log2(e) for the SiLU conv prologue)
 // =================================================================================================
-static inline int gn_nslab(int HW) { int n = HW / 64; return n < 1 ? 1 : (n > 64 ? 64 : n); }
-size_t gn_partial_bytes(int B, int HW, int C) { return (size_t)B * gn_nslab(HW) * C * 2 * sizeof(float); }
+int gn_default_nslab(int HW) { int n = HW / 64; return n < 1 ? 1 : (n > 64 ? 64 : n); }
+size_t gn_stats_bytes(int B, int nslab, int C) { return (size_t)B * nslab * C * 4 * sizeof(float); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int xs, int C, int HW, int nslab, int c_off, int c_total,
-                                                         float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int xs, int C, int HW, int nslab, float4* __restrict__ stats) {
     constexpr int VEC = TI<T>::VEC;
     __shared__ float red[256 * VEC * 2];
     const int cols = C / VEC;                         // 16-byte channel vectors per pixel
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     const int c = (cb * 256 + col) * VEC;
     float s1[VEC], s2[VEC], piv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; piv[e] = 0.f; }
     if (row < rows) {
         const T* base = x + (long long)b * HW * xs + c;
-        { uint4 u = *(const uint4*)base; TI<T>::unpack(u, piv); }
+        { uint4 u = *(const uint4*)(base + (long long)p0 * xs); TI<T>::unpack(u, piv); }
         for (int p = p0 + row; p < p1; p += rows) {
             const uint4 u = *(const uint4*)(base + (long long)p * xs);
             float f[VEC];
@@ -262,34 +264,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { s1[e] += red[(o + e) * 2]; s2[e] += red[(o + e) * 2 + 1]; }
         }
-        float* dst = partial + (((long long)b * nslab + slab) * c_total + c_off + c) * 2;
+        float4* dst = stats + ((long long)b * nslab + slab) * C + c;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+        for (int e = 0; e < VEC; ++e) dst[e] = make_float4(piv[e], s1[e], s2[e], (float)(p1 - p0));
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
-                                                         int nslab, const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps, float premul, float* __restrict__ scale,
-                                                         float* __restrict__ shift) {
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1,
+                                                         int C, int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float premul, float* __restrict__ scale, float* __restrict__ shift) {
     const int g = blockIdx.x, b = blockIdx.y;
-    const int gw = C / 32;
+    const int gw = C / 32, C1 = C - C0;
     const int lane = threadIdx.x;
-    auto pivot = [&](int c) -> float {
-        return (c < C0) ? TI<T>::ld(x0, (long long)b * HW * xs0 + c) : TI<T>::ld(x1, (long long)b * HW * xs1 + (c - C0));
-    };
-    const double kg = (double)pivot(g * gw);
+    const int cg0 = g * gw;
+    const double kg = (cg0 < C0) ? (double)st0[((long long)b * nslab0) * C0 + cg0].x : (double)st1[((long long)b * nslab1) * C1 + (cg0 - C0)].x;
     double S1 = 0.0, S2 = 0.0;
-    const int items = gw * nslab;
-    const double npix = (double)(HW / nslab);
+    // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
+    const int n0c = max(0, min(C0 - cg0, gw));        // channels of this group that live in tensor 0
+    const int items0 = n0c * nslab0, items = items0 + (gw - n0c) * nslab1;
     for (int it = lane; it < items; it += 64) {
-        const int ci = it / nslab, sl = it % nslab;
-        const int c = g * gw + ci;
-        const float* pp = partial + (((long long)b * nslab + sl) * C + c) * 2;
-        const double n = (sl == nslab - 1) ? (double)(HW - (nslab - 1) * (HW / nslab)) : npix;
-        const double d = (double)pivot(c) - kg;
-        const double a1 = (double)pp[0], a2 = (double)pp[1];
+        float4 v;
+        if (it < items0) { const int ci = it / nslab0, sl = it % nslab0; v = st0[((long long)b * nslab0 + sl) * C0 + cg0 + ci]; }
+        else { const int j = it - items0; const int ci = n0c + j / nslab1, sl = j % nslab1; v = st1[((long long)b * nslab1 + sl) * C1 + (cg0 + ci - C0)]; }
+        const double n = (double)v.w, d = (double)v.x - kg, a1 = (double)v.y, a2 = (double)v.z;
         S1 += a1 + n * d;
         S2 += a2 + 2.0 * d * a1 + n * d * d;
     }
@@ -305,42 +302,35 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const T* __restrict__ x
     const float mean = (float)(kg + m);
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int ci = lane; ci < gw; ci += 64) {
-        const int c = g * gw + ci;
+        const int c = cg0 + ci;
         const float sc = rstd * gamma[c];
         scale[(long long)b * C + c] = sc * premul;
         shift[(long long)b * C + c] = (beta[c] - mean * sc) * premul;
     }
 }
 
-template <typename T>
-static int gn_launch(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, float premul, float* partial, float* scale, float* shift,
-                     hipStream_t s) {
-    constexpr int VEC = TI<T>::VEC;
-    const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1;
-    const int HW = x0.H * x0.W;
-    if (C != nw.c || C % 32) WDM_FAIL(WDM_EINVAL, "groupnorm: %d channels vs %d weights (must be a multiple of 32)", C, nw.c);
-    if (C0 % VEC || C1 % VEC) WDM_FAIL(WDM_EINVAL, "groupnorm: channel counts must be multiples of %d", VEC);
-    const int nslab = gn_nslab(HW);
-    {
-        const int cols = C0 / VEC;
-        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0.p, x0.xs, C0, HW, nslab, 0, C, partial);
-    }
-    if (C1) {
-        const int cols = C1 / VEC;
-        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x1->p, x1->xs, C1, HW, nslab, C0, C, partial);
-    }
-    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(32, B), dim3(64), 0, s, (const T*)x0.p, x0.xs, C0, x1 ? (const T*)x1->p : (const T*)x0.p, x1 ? x1->xs : 0, C,
-                       HW, nslab, partial, nw.g, nw.b, eps, premul, scale, shift);
+int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s) {
+    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const int HW = x.H * x.W;
+    if (x.C % vec) WDM_FAIL(WDM_EINVAL, "groupnorm: channel count %d must be a multiple of %d", x.C, vec);
+    const int cols = x.C / vec;
+    const dim3 grid(nslab, B, (cols + 255) / 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nslab, (float4*)stats);
+    else hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nslab, (float4*)stats);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
 
-int k_gn_scale_shift(const Tens& x0, const Tens* x1, int B, const NormW& nw, float eps, int for_silu_conv, float* partial, float* scale, float* shift,
-                     int dtype, hipStream_t s) {
+int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw, float eps, int for_silu_conv,
+                  float* scale, float* shift, hipStream_t s) {
+    const int C = C0 + C1;
+    if (C != nw.c || C % 32) WDM_FAIL(WDM_EINVAL, "groupnorm: %d channels vs %d weights (must be a multiple of 32)", C, nw.c);
     // for_silu_conv: the consumer is a conv with the fused GN+SiLU prologue, which wants scale/shift pre-multiplied by -log2(e)
     const float premul = for_silu_conv ? -1.4426950408889634f : 1.0f;
-    return dtype == WDM_BF16 ? gn_launch<__bf16>(x0, x1, B, nw, eps, premul, partial, scale, shift, s)
-                             : gn_launch<float>(x0, x1, B, nw, eps, premul, partial, scale, shift, s);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW,
+                       nw.g, nw.b, eps, premul, scale, shift);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
 }
 
 // GroupNorm apply without activation (AttnBlock.norm, unet.py:169-170): y = x*scale + shift, NHWC dense output

@@ -222,7 +222,7 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
     x.p = (void*)x96; x.C = cfg.in_channels; x.H = R; x.W = R; x.xs = cfg.in_channels;
     std::vector<Tens> hs;
     Tens h;
-    WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr));
+    WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr, true));
     hs.push_back(h);
     for (int l = 0; l < nres; ++l) {
         for (int b = 0; b < nrb; ++b) {
@@ -238,7 +238,7 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         }
         if (l != nres - 1) {
             Tens o;
-            WDM_TRY(run_conv(c, cw(down_ds[l]), MODE_S2, hs.back(), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr));
+            WDM_TRY(run_conv(c, cw(down_ds[l]), MODE_S2, hs.back(), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr, true));
             hs.push_back(o);
         }
     }
@@ -268,19 +268,15 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         }
         if (l != 0) {
             Tens o;
-            WDM_TRY(run_conv(c, cw(up_us[l]), MODE_UPS, h, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr));
+            WDM_TRY(run_conv(c, cw(up_us[l]), MODE_UPS, h, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr, true));
             free_tens(c, h);
             h = o;
         }
     }
     // ---- norm_out -> SiLU -> conv_out, written as NCHW fp32 (the reference's output layout)
     {
-        float *sc, *sh, *partial;
-        WDM_TRY(af((size_t)c.B * h.C, &sc));
-        WDM_TRY(af((size_t)c.B * h.C, &sh));
-        WDM_TRY(af(gn_partial_bytes(c.B, h.H * h.W, h.C) / 4, &partial));
-        if (!c.dry) WDM_TRY(k_gn_scale_shift(h, nullptr, c.B, nw(norm_out), 1e-6f, 1, partial, sc, sh, c.dtype, c.s));
-        c.ar->free(partial);
+        float *sc, *sh;
+        WDM_TRY(run_gn(c, nw(norm_out), h, nullptr, 1, &sc, &sh));
         Tens dummy;
         WDM_TRY(run_conv(c, cw(conv_out), MODE_S1, h, nullptr, sc, sh, nullptr, 0, 0, nullptr, &dummy, Y_NCHW_F32, eps_out));
         c.ar->free(sc); c.ar->free(sh);
