@@ -138,8 +138,18 @@ def main():
         dom = rep[0]
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = dom["flops"] / dom["ms"] / 1e9
+        # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
+        # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+            traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": dom["kernel"], "launches": dom["launches"],
+                    "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_traffic.json)",
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                    "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "all_conv_tflops": round(sum(e["flops"] for e in rep) / tot_ms / 1e9, 2),
