@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c4"],
+                    help="c1: BASELINE configs[1] (default, the headline metric); c2: 128x128 patches, batch 256; "
+                         "c4: whole 480x720 images, 45 stitched patches each, 50 DDIM steps (informational extra runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -66,10 +69,15 @@ def main():
     from wavedm_amd import _lib, parallel
     from wavedm_amd import procedural as P
 
-    cfg = P.raindrop_wavelet_config()
+    if args.workload == "c2":
+        args.batch = 256 if args.batch == 64 else args.batch
+    if args.workload == "c4":
+        args.ddim_steps = 50 if args.ddim_steps == 100 else args.ddim_steps
+        args.batch = 1 if args.batch == 64 else args.batch
+    cfg = P.raindrop_wavelet_config(image_size=128 if args.workload == "c2" else 64)
     cfg.device = dev
     a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_rank, image_folder="/tmp/wdm",
-                        test_set="raindrop", grid_r=16, max_batch=args.batch)
+                        test_set="raindrop", grid_r=16, max_batch=max(args.batch, 64))
     t0 = time.time()
     d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, dtype=args.dtype)
     sd = None
@@ -85,11 +93,24 @@ def main():
             f"packed {d.model.packed_bytes() / 1e6:.0f} MB, dtype {args.dtype})")
 
     B = args.batch
-    rainy, x_T = P.synthetic_batch(B, patch_px=256, seed=61 + rank)
-    rainy, x_T = rainy.to(dev), x_T.to(dev)
+    if args.workload == "c4":
+        # whole images: DWT -> 45 overlapping 64x64 patches (r = 16) per image through the stitched sampler -> IDWT
+        g = torch.Generator().manual_seed(61 + rank)
+        imgs = [torch.rand(1, 6, 480, 720, generator=g) for _ in range(B)]
+        restorer = wavedm_amd.DiffusiveRestoration(d, a, cfg, save_images=False)
+        loader = [(im, f"img{k}", torch.zeros(1)) for k, im in enumerate(imgs)]
 
-    def one_pass():
-        return d.restore_batch(rainy, x_T)
+        def one_pass():
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                outs, _ = restorer.restore(loader, validation="raindrop", r=16)
+            return outs[-1], None, None
+    else:
+        rainy, x_T = P.synthetic_batch(B, patch_px=4 * cfg.data.image_size, seed=61 + rank)
+        rainy, x_T = rainy.to(dev), x_T.to(dev)
+
+        def one_pass():
+            return d.restore_batch(rainy, x_T)
 
     def fence():
         torch.cuda.synchronize()
@@ -157,7 +178,7 @@ def main():
 
     # ---- CPU baseline leg: the oracle on this box's host cores, bounded sample (BASELINE configs[0])
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c1":
         from oracle import wavedm_oracle as O
         nb, ns = 4, 10
         r4, xt4 = P.synthetic_batch(nb, patch_px=256, seed=61)
@@ -188,7 +209,8 @@ def main():
     if rank == 0:
         total_imgs = B * world * args.steps
         res = {
-            "metric": "restored images/sec, raindrop 64x64 patches, 100-step DDIM",
+            "metric": "restored images/sec, raindrop 64x64 patches, 100-step DDIM" if args.workload == "c1" else
+                      f"restored images/sec, workload {args.workload} (informational, not the headline metric)",
             "value": round(total_imgs / elapsed, 3),
             "unit": "img/s",
             "n_gpus": world,
@@ -200,8 +222,10 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (seeded U[0,1) 256x256 crops, procedural random-init weights of the raindrop_wavelet UNet)",
-            "config": {"workload": f"raindrop_wavelet 64x64 (256x256 px crops), batch {B}/GPU, {args.ddim_steps} DDIM steps, "
-                                   f"DWT + UNet x{args.ddim_steps} + IDWT (BASELINE.json configs[1]{' x N, configs[3]' if world > 1 else ''})",
+            "config": {"workload": (f"raindrop_wavelet 64x64 (256x256 px crops), batch {B}/GPU, {args.ddim_steps} DDIM steps, "
+                                    f"DWT + UNet x{args.ddim_steps} + IDWT (BASELINE.json configs[1]{' x N, configs[3]' if world > 1 else ''})") if args.workload == "c1"
+                       else (f"raindrop_wavelet 128x128 patches, batch {B}/GPU, {args.ddim_steps} DDIM steps (BASELINE.json configs[2])" if args.workload == "c2"
+                             else f"{B} full 480x720 image(s)/GPU, 45 stitched 64x64 patches each, {args.ddim_steps} DDIM steps (BASELINE.json configs[4])"),
                        "global_batch": B * world, "ddim_steps": args.ddim_steps, "parallelism": f"image-sharded x{world}",
                        "outputs_finite": finite},
             "roofline": roofline,
