@@ -79,7 +79,7 @@ def main():
     a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_rank, image_folder="/tmp/wdm",
                         test_set="raindrop", grid_r=16, max_batch=max(args.batch, 64))
     t0 = time.time()
-    d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, dtype=args.dtype)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=args.dtype)   # HFRM: identity stand-in
     sd = None
     if rank == 0:
         sd = P.procedural_state_dict(cfg, seed=61)          # random-init weights of the named architecture

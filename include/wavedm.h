@@ -161,6 +161,34 @@ int wdm_temb_forward(wdm_handle* h, const float* t, int n_t, int ch, const float
                      const float* w1, const float* b1, float* temb_out, void* scratch, size_t scratch_bytes,
                      void* stream);
 
+/* ---- HFRM -------------------------------------------------------------------
+ * Replaces HFRM.__init__/forward, models/arch.py:206-253 (the module restoration.py:94 runs once per image to
+ * produce the 45 "other" wavelet channels).  Same protocol as the UNet object: enumerate the state_dict keys,
+ * give one caller-allocated buffer, load fp32 parameters, finalize (packs the GEMM weights, folds beta/gamma),
+ * forward on NCHW f32 images whose H and W are multiples of 16. */
+typedef struct wdm_hfrm wdm_hfrm;
+typedef struct wdm_hfrm_config {
+    int in_channel;          /* 3 */
+    int dim;                 /* 32 */
+    int mid_blk_num;         /* 6 */
+    int n_enc;               /* 4 */
+    int enc_blk_nums[8];     /* 2,2,2,4 (models/ddm_wavelet.py:139) */
+    int n_dec;               /* 4 */
+    int dec_blk_nums[8];     /* 2,2,2,2 */
+    int dtype;
+} wdm_hfrm_config;
+int wdm_hfrm_create(wdm_handle* h, const wdm_hfrm_config* cfg, wdm_hfrm** out);
+int wdm_hfrm_destroy(wdm_hfrm* m);
+int wdm_hfrm_num_params(const wdm_hfrm* m);
+int wdm_hfrm_param_info(const wdm_hfrm* m, int i, const char** name, int* ndim, int64_t shape[4]);
+size_t wdm_hfrm_packed_bytes(const wdm_hfrm* m);
+int wdm_hfrm_set_packed(wdm_hfrm* m, void* packed, size_t bytes);
+int wdm_hfrm_load_param(wdm_hfrm* m, const char* name, const float* dev_src, int64_t numel, void* stream);
+int wdm_hfrm_finalize(wdm_hfrm* m, void* stream);
+size_t wdm_hfrm_workspace_bytes(const wdm_hfrm* m, int B, int H, int W);
+int wdm_hfrm_forward(wdm_hfrm* m, const float* x, int B, int H, int W, float* y, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
  * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).

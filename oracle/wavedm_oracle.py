@@ -324,3 +324,56 @@ def restore(sd, config, x01, x_T, sampling_timesteps, r=16, hfrm=None, keep=-5):
 def torch_psnr(tar, prd):          # utils/metrics.py:7-11
     d = torch.clamp(prd, 0, 1) - torch.clamp(tar, 0, 1)
     return 20 * torch.log10(1 / (d ** 2).mean().sqrt())
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY.md §8(f)-1  HFRM high-frequency refinement module   (reference: models/arch.py:132-253)
+# ----------------------------------------------------------------------------------------------
+HFRM_DEFAULT = dict(in_channel=3, dim=32, mid_blk_num=6, enc_blk_nums=(2, 2, 2, 4), dec_blk_nums=(2, 2, 2, 2))   # ddm_wavelet.py:137-142
+
+
+def layernorm2d(sd, name, x, eps=1e-6):
+    """arch.py:7-43: per-pixel normalisation over the channel axis, biased variance, affine."""
+    mu = x.mean(1, keepdim=True)
+    var = (x - mu).pow(2).mean(1, keepdim=True)
+    y = (x - mu) / (var + eps).sqrt()
+    return sd[name + ".weight"].view(1, -1, 1, 1) * y + sd[name + ".bias"].view(1, -1, 1, 1)
+
+
+def hfrm_block(sd, name, x):
+    """ResidualBlock, arch.py:158-204."""
+    dim = x.shape[1]
+    h = layernorm2d(sd, name + ".norm1", x)
+    h = conv(sd, name + ".conv1", h)                                                          # 1x1 dim -> 2 dim
+    h = F.conv2d(h, sd[name + ".conv2.weight"], sd[name + ".conv2.bias"], padding=1, groups=2 * dim)   # depthwise 3x3
+    h = h[:, :dim] * h[:, dim:]                                                               # SpatialAttn (gate)
+    s = conv(sd, name + ".channel_attn.chan_conv", F.adaptive_avg_pool2d(h, 1))               # ChannelAttn
+    h = h * s
+    h = conv(sd, name + ".conv3", h)
+    y = x + h * sd[name + ".beta"]
+    h = conv(sd, name + ".conv4", layernorm2d(sd, name + ".norm2", y))
+    h = h[:, :dim] * h[:, dim:]
+    h = conv(sd, name + ".conv5", h)
+    return y + h * sd[name + ".gamma"]
+
+
+def hfrm_forward(sd, x, enc_blk_nums=(2, 2, 2, 4), mid_blk_num=6, dec_blk_nums=(2, 2, 2, 2)):
+    """HFRM.forward, arch.py:235-253.  x: (B,3,H,W) raw [0,1] image, H and W multiples of 16."""
+    B, C, H, W = x.shape
+    inp = x
+    x = conv(sd, "conv_in", x, padding=1)
+    encs = []
+    for i, num in enumerate(enc_blk_nums):
+        for j in range(num):
+            x = hfrm_block(sd, f"encoders.{i}.{j}", x)
+        encs.append(x)
+        x = conv(sd, f"downs.{i}", x, stride=2)                                               # 2x2 stride 2
+    for j in range(mid_blk_num):
+        x = hfrm_block(sd, f"mid_blks.{j}", x)
+    for i, (num, skip) in enumerate(zip(dec_blk_nums, encs[::-1])):
+        x = F.pixel_shuffle(F.conv2d(x, sd[f"ups.{i}.0.weight"]), 2)                          # 1x1 (no bias) + PixelShuffle(2)
+        x = x + skip
+        for j in range(num):
+            x = hfrm_block(sd, f"decoders.{i}.{j}", x)
+    x = conv(sd, "conv_out", x, padding=1)
+    return (x + inp)[:, :, :H, :W]

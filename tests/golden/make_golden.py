@@ -89,6 +89,7 @@ def block_sd(prefix, shapes, seed=61):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true", help="skip the full-width (156 M) cases")
+    ap.add_argument("--only-hfrm", action="store_true", help="regenerate hfrm.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -103,6 +104,35 @@ def main():
     torch.set_grad_enabled(False)
 
     out = lambda n: os.path.join(HERE, n)
+
+    # ------------------------------------------------------------------ HFRM (models/arch.py)
+    def golden_hfrm():
+        print("[hfrm]")
+        from models.arch import HFRM
+        sd_h = P.procedural_hfrm_state_dict(seed=61)
+        gen = HFRM(in_channel=3, dim=32, mid_blk_num=6, enc_blk_nums=[2, 2, 2, 4], dec_blk_nums=[2, 2, 2, 2]).eval()
+        assert list(gen.state_dict().keys()) == list(sd_h.keys())
+        gen.load_state_dict(sd_h, strict=True)
+        hf = {"n_params": np.array(sum(v.numel() for v in sd_h.values()), dtype=np.int64)}
+        for tag, shape, seed in (("a", (2, 3, 32, 48), 91), ("b", (1, 3, 64, 64), 92)):
+            x = seeded(shape, seed, "rand")
+            y = gen(x)
+            check(f"hfrm forward {tag}", O.hfrm_forward(sd_h, x), y)
+            hf["y_" + tag] = y.numpy()
+            hf["shape_" + tag] = np.array(shape, dtype=np.int32)
+            hf["seed_" + tag] = np.array(seed, dtype=np.int32)
+        # one block in isolation (NAFBlock-style, arch.py:132-204) at d = 64
+        blk = gen.encoders[1][0]
+        xb = seeded((2, 64, 16, 24), 93)
+        yb = blk(xb)
+        check("hfrm block", O.hfrm_block(sd_h, "encoders.1.0", xb), yb)
+        hf["blk_y"] = yb.numpy()
+        np.savez_compressed(out("hfrm.npz"), **hf)
+
+    if args.only_hfrm:
+        golden_hfrm()
+        return
+    golden_hfrm()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")

@@ -25,13 +25,13 @@ def build(cfg, dtype):
     return net.cuda()
 
 
-def make_diffusion(cfg, dtype, S):
+def make_diffusion(cfg, dtype, S, generator=lambda x: x):
     from types import SimpleNamespace
     import wavedm_amd
     from wavedm_amd import procedural as P
     cfg.device = torch.device("cuda", 0)
     args = SimpleNamespace(resume="", sampling_timesteps=S, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=16)
-    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, dtype=dtype)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=generator, dtype=dtype)
     d.model.load_state_dict(P.procedural_state_dict(cfg), strict=True)
     return d, args
 
@@ -65,6 +65,9 @@ def test_reduced_sampler(golden, dtype):
     xs, x0 = d.sample_image(xc, x_T[:1].cuda(), x_other=xc[:, 3:].contiguous(), last=False, patch_locs=[(0, 0)], patch_size=16, use_other=True)
     assert len(xs) == 11 and len(x0) == 10
     assert torch.equal(xs[-1], xs_last[:1]) and torch.equal(x0[-5], x0m5[:1])
+    # opt-in early stop: the 4 steps after x0_preds[-5] are skipped, the kept prediction is identical
+    out_es, _, x0_es = d.restore_batch(rainy.cuda(), x_T.cuda(), early_stop=True)
+    assert torch.equal(x0_es, x0m5) and torch.equal(out_es, out)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

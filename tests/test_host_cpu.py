@@ -80,3 +80,16 @@ def test_sampler_host_arithmetic_matches_oracle():
         assert float(sampling.compute_alpha(b, torch.tensor([t])).flatten()[0]) == float(O.compute_alpha(b, t))
     for (h, w, p, r) in [(64, 64, 64, 16), (120, 180, 64, 16), (65, 70, 64, 16), (30, 45, 16, 4)]:
         assert sampling.overlapping_grid_indices(h, w, p, r) == O.overlapping_grid_indices(h, w, p, r)
+
+
+def test_hfrm_param_table_matches_reference_state_dict_layout():
+    """wdm_hfrm_param_info enumerates the reference HFRM's state_dict keys in registration order (arch.py:206-233)."""
+    from wavedm_amd.arch import HFRM
+    m = HFRM(in_channel=3, dim=32, mid_blk_num=6, enc_blk_nums=[2, 2, 2, 4], dec_blk_nums=[2, 2, 2, 2])
+    want = P.hfrm_param_shapes()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(want.keys())
+    assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    assert sum(v.numel() for v in sd.values()) == 15941667
+    with pytest.raises(RuntimeError):
+        m.pack_weights()              # CPU parameters: no CPU path

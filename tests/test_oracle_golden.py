@@ -129,3 +129,15 @@ def test_param_layout_full():
     assert len(shapes) == 332
     assert sum(int(np.prod(s)) for s in shapes.values()) == 156492675
     assert P.unet_in_channels(cfg) == 96
+
+
+def test_hfrm_matches_reference_golden(golden):
+    """oracle HFRM (models/arch.py restated) == the reference HFRM's outputs, procedural weights."""
+    g = golden("hfrm.npz")
+    sd = P.procedural_hfrm_state_dict(seed=61)
+    assert int(g["n_params"]) == sum(v.numel() for v in sd.values()) == 15941667
+    for tag in ("a", "b"):
+        x = seeded(tuple(int(v) for v in g["shape_" + tag]), int(g["seed_" + tag]), "rand")
+        assert rel_linf(O.hfrm_forward(sd, x), torch.from_numpy(g["y_" + tag])) <= 1e-5
+    xb = seeded((2, 64, 16, 24), 93)
+    assert rel_linf(O.hfrm_block(sd, "encoders.1.0", xb), torch.from_numpy(g["blk_y"])) <= 1e-5

@@ -23,6 +23,11 @@ class UNetConfig(C.Structure):
                 ("out_ch", C.c_int), ("resolution", C.c_int), ("resamp_with_conv", C.c_int), ("dtype", C.c_int)]
 
 
+class HFRMConfig(C.Structure):
+    _fields_ = [("in_channel", C.c_int), ("dim", C.c_int), ("mid_blk_num", C.c_int), ("n_enc", C.c_int),
+                ("enc_blk_nums", C.c_int * 8), ("n_dec", C.c_int), ("dec_blk_nums", C.c_int * 8), ("dtype", C.c_int)]
+
+
 class ResblockParams(C.Structure):
     _fields_ = [("cin", C.c_int), ("cout", C.c_int)] + [(n, C.c_void_p) for n in (
         "norm1_w", "norm1_b", "conv1_w", "conv1_b", "temb_w", "temb_b", "norm2_w", "norm2_b", "conv2_w", "conv2_b",
@@ -75,6 +80,16 @@ def lib():
         "wdm_attn_forward": (i, [vp, C.POINTER(AttnParams), vp, i, i, i, vp, i, vp, sz, vp]),
         "wdm_conv_forward": (i, [vp, vp, vp, i, i, i, vp, i, i, i, vp, i, vp, sz, vp]),
         "wdm_temb_forward": (i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "wdm_hfrm_create": (i, [vp, C.POINTER(HFRMConfig), C.POINTER(vp)]),
+        "wdm_hfrm_destroy": (i, [vp]),
+        "wdm_hfrm_num_params": (i, [vp]),
+        "wdm_hfrm_param_info": (i, [vp, i, C.POINTER(C.c_char_p), C.POINTER(i), C.POINTER(i64 * 4)]),
+        "wdm_hfrm_packed_bytes": (sz, [vp]),
+        "wdm_hfrm_set_packed": (i, [vp, vp, sz]),
+        "wdm_hfrm_load_param": (i, [vp, C.c_char_p, vp, i64, vp]),
+        "wdm_hfrm_finalize": (i, [vp, vp]),
+        "wdm_hfrm_workspace_bytes": (sz, [vp, i, i, i]),
+        "wdm_hfrm_forward": (i, [vp, vp, i, i, i, vp, vp, sz, vp]),
         "wdm_prof_enable": (i, [i]),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
@@ -92,7 +107,9 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_unet_destroy", "wdm_unet_num_params", "wdm_unet_param_info", "wdm_unet_packed_bytes",
             "wdm_unet_set_packed", "wdm_unet_load_param", "wdm_unet_mark_loaded", "wdm_unet_workspace_bytes",
             "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
-            "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
+            "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
+            "wdm_hfrm_forward", "wdm_prof_enable", "wdm_prof_report"]
 
 
 def prof_enable(on: bool):

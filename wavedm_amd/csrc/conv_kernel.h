@@ -81,6 +81,8 @@ struct ConvArgs {
     float* stats;          // optional: GroupNorm partial statistics of the output, float4[B][stats_nslab][Cout] (see elementwise.hip)
     int stats_nslab;       // slabs per image = tiles per image x wave tiles (in M) per tile
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
+    long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
+                           //    (plain GEMMs over M rows that do not fill the last row of the 16-wide pixel grid)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -217,7 +219,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 const int img = m / (TH * TW), rr = m % (TH * TW);
                 const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
                 const int img_g = img0 + img;
-                const bool valid = n < a.Cout && img_g < a.B;
+                const bool valid = n < a.Cout && img_g < a.B &&
+                                   (a.m_valid == 0 || ((long long)img_g * a.Hout + oy) * a.Wout + ox < a.m_valid);
                 if (!valid && !do_stats) continue;
                 const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -311,6 +314,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 const int img_g = img0 + img;
                 if (img_g >= a.B) continue;
                 const long long opix = ((long long)img_g * a.Hout + oy) * a.Wout + ox;
+                if (a.m_valid != 0 && opix >= a.m_valid) continue;
 #pragma unroll 4
                 for (int c = 0; c < ECOLS; ++c) {
                     const int n = ncol0 + c;

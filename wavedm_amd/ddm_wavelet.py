@@ -5,8 +5,11 @@ Kept: constructor `(args, config)`, attributes `.model .wavelet_dec .wavelet_rec
 .betas .num_timesteps .device`, `sample_image(...)`, `diffusive_restoration(...)`,
 `overlapping_grid_indices(...)`, `generalized_steps_overlapping(...)`, `load_ddm_ckpt(path, ema)`
 and the checkpoint dict format (`state_dict` with the reference's keys, optional `ema_helper`).
-Not rebuilt: training (`train`) and the HFRM network -- `.generator` is whatever
-callable the user passes (`generator=`); default = identity, the stand-in BASELINE.md §3 names.
+`.generator` is the HFRM (`wavedm_amd.arch.HFRM`, same constructor arguments as ddm_wavelet.py:137-142) loaded from
+`saved_models/raindrop/lastest.pth` (or `args.hfrm_ckpt`) when that file exists; the reference ships no such file
+(SURVEY.md §4), so without one the identity stand-in BASELINE.md §3 names is used and a warning says so.
+`generator=` overrides both: any callable, or "procedural" for an HFRM with seeded weights (tests, bench).
+Not rebuilt: training (`train`).
 Deliberate differences: the model is NOT wrapped in DistributedDataParallel (inference needs no
 gradient all-reduce; `.model.module` is provided for callers that unwrap), outputs stay on the
 GPU (no per-step `.to('cpu')`), and the per-step statistics print is opt-in (`verbose=True`)."""
@@ -41,7 +44,7 @@ class DenoisingDiffusion_Wavelet(object):
 
         self.wavelet_dec = WaveletTransform(scale=2, dec=True)
         self.wavelet_rec = WaveletTransform(scale=2, dec=False)
-        self.generator = generator if generator is not None else (lambda x: x)   # HFRM stand-in (out of scope)
+        self.generator = self._make_generator(generator, dtype)
 
         if getattr(config.data, "global_attn", False):
             raise NotImplementedError("data.global_attn=True (DiffusionUNet_Global) is outside the accelerated path")
@@ -57,6 +60,29 @@ class DenoisingDiffusion_Wavelet(object):
             beta_end=config.diffusion.beta_end, num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
         self.betas = torch.from_numpy(betas).float().to(self.device)
         self.num_timesteps = self.betas.shape[0]
+
+    # ---- HFRM (ddm_wavelet.py:137-147) -------------------------------------------------------------
+    HFRM_ARGS = dict(in_channel=3, dim=32, mid_blk_num=6, enc_blk_nums=[2, 2, 2, 4], dec_blk_nums=[2, 2, 2, 2])
+
+    def _make_generator(self, generator, dtype):
+        if callable(generator):
+            return generator
+        from .arch import HFRM
+        if generator == "procedural":
+            from .procedural import procedural_hfrm_state_dict
+            g = HFRM(**self.HFRM_ARGS, dtype=dtype)
+            g.load_state_dict(procedural_hfrm_state_dict(seed=getattr(self.args, "seed", 61)), strict=True)
+            return g.to(self.device).eval().requires_grad_(False)
+        if generator is not None:
+            raise ValueError("generator must be a callable, 'procedural' or None")
+        path = getattr(self.args, "hfrm_ckpt", None) or "saved_models/raindrop/lastest.pth"
+        if os.path.isfile(path):
+            g = HFRM(**self.HFRM_ARGS, dtype=dtype)
+            g.load_state_dict(torch.load(path, map_location="cpu", weights_only=False), strict=True)
+            return g.to(self.device).eval().requires_grad_(False)
+        import warnings
+        warnings.warn(f"HFRM checkpoint {path!r} not found: using the identity stand-in for .generator", stacklevel=3)
+        return lambda x: x
 
     # ---- checkpoint (utils/logging.py:21-29 + ddm_wavelet.py:180-190) -------------------------
     def load_ddm_ckpt(self, load_path, ema=False):
@@ -127,7 +153,7 @@ class DenoisingDiffusion_Wavelet(object):
                                  total=total, use_global=use_global, use_other=use_other)
 
     # ---- batched independent crops (BASELINE.json configs 0-3) --------------------------------------------
-    def restore_batch(self, rainy01, x_T, hfrm_out01=None, keep=-5):
+    def restore_batch(self, rainy01, x_T, hfrm_out01=None, keep=-5, early_stop=False):
         """B independent patch_size x patch_size crops: DWT -> S-step DDIM -> IDWT, all on the GPU.
 
         rainy01 (B,3,4R,4R) in [0,1]; x_T (B,3,R,R) start noise; returns the restored (B,3,4R,4R) in [0,1] built
@@ -140,8 +166,9 @@ class DenoisingDiffusion_Wavelet(object):
         skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
         seq = list(range(0, self.config.diffusion.num_diffusion_timesteps, skip))
         xs, x0_preds = sampling.ddim_sample(self.model, x_T, x_cond, x_other, seq, self.betas, corners=None,
-                                            max_batch=getattr(self.args, "max_batch", 64))
+                                            max_batch=getattr(self.args, "max_batch", 64),
+                                            stop_at=keep if early_stop else None)      # early_stop: skip the discarded tail
         pc = self.config.model.pred_channels
         x0 = x0_preds[keep]
         out = torch.cat([x0[:, :pc], hf_wav[:, pc:]], dim=1)
-        return inverse_data_transform(self.wavelet_rec(out)), xs[-1], x0
+        return inverse_data_transform(self.wavelet_rec(out)), (xs[-1] if xs[-1] is not None else xs[len(seq) + keep + 1]), x0

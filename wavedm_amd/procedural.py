@@ -194,3 +194,58 @@ def synthetic_batch(batch: int, patch_px: int = 256, seed: int = 61):
     rainy = torch.rand(batch, 3, patch_px, patch_px, generator=g, dtype=torch.float32)
     x_T = torch.randn(batch, 3, patch_px // 4, patch_px // 4, generator=g, dtype=torch.float32)
     return rainy, x_T
+
+
+# ----------------------------------------------------------------------------------------------
+# HFRM (models/arch.py:206-253) parameter layout + procedural values
+# ----------------------------------------------------------------------------------------------
+def hfrm_param_shapes(in_channel=3, dim=32, mid_blk_num=6, enc_blk_nums=(2, 2, 2, 4), dec_blk_nums=(2, 2, 2, 2)):
+    """Ordered {state_dict key: shape} of the reference HFRM (448 tensors, 15.94 M parameters at the defaults)."""
+    shapes = OrderedDict()
+
+    def block(name, d):
+        shapes[name + ".beta"] = (1, d, 1, 1)
+        shapes[name + ".gamma"] = (1, d, 1, 1)
+        for cname, co, ci, k in (("conv1", 2 * d, d, 1), ("conv2", 2 * d, 1, 3), ("conv3", d, d, 1),
+                                 ("channel_attn.chan_conv", d, d, 1), ("conv4", 2 * d, d, 1), ("conv5", d, d, 1)):
+            shapes[f"{name}.{cname}.weight"] = (co, ci, k, k)
+            shapes[f"{name}.{cname}.bias"] = (co,)
+        for n in ("norm1", "norm2"):
+            shapes[f"{name}.{n}.weight"] = (d,)
+            shapes[f"{name}.{n}.bias"] = (d,)
+
+    shapes["conv_in.weight"] = (dim, in_channel, 3, 3)
+    shapes["conv_in.bias"] = (dim,)
+    d = dim
+    enc, downs = OrderedDict(), OrderedDict()
+    saved = shapes
+    for i, num in enumerate(enc_blk_nums):
+        shapes = enc
+        for j in range(num):
+            block(f"encoders.{i}.{j}", d)
+        downs[f"downs.{i}.weight"] = (2 * d, d, 2, 2)
+        downs[f"downs.{i}.bias"] = (2 * d,)
+        d *= 2
+    mid = OrderedDict()
+    shapes = mid
+    for j in range(mid_blk_num):
+        block(f"mid_blks.{j}", d)
+    ups, dec = OrderedDict(), OrderedDict()
+    for i, num in enumerate(dec_blk_nums):
+        ups[f"ups.{i}.0.weight"] = (2 * d, d, 1, 1)
+        d //= 2
+        shapes = dec
+        for j in range(num):
+            block(f"decoders.{i}.{j}", d)
+    shapes = saved
+    # registration order of the reference: conv_in, encoders, decoders, mid_blks, ups, downs, conv_out
+    for part in (enc, dec, mid, ups, downs):
+        shapes.update(part)
+    shapes["conv_out.weight"] = (in_channel, d, 3, 3)
+    shapes["conv_out.bias"] = (in_channel,)
+    return shapes
+
+
+def procedural_hfrm_state_dict(seed: int = 61, **kw):
+    import torch
+    return OrderedDict((k, torch.from_numpy(procedural_tensor("hfrm." + k, s, seed))) for k, s in hfrm_param_shapes(**kw).items())

@@ -57,7 +57,7 @@ def overlapping_grid_indices(h, w, output_size, r=None):
     return h_list, w_list
 
 
-def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all"):
+def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None):
     """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
 
     x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
@@ -66,6 +66,9 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
              or a list of (img, hi, wi).
     keep: "all" -> (xs, x0_preds) lists as the reference returns; or a set of negative indices into
           x0_preds / xs to retain, e.g. {-5, -1} (saves nothing but list bookkeeping).
+    stop_at: opt-in early stop: a negative index k means "x0_preds[k] is all the caller needs", so the
+          |k|-1 steps after it -- which the reference computes and discards (restoration.py:108 uses [-5]) -- are skipped;
+          the lists are padded with None so indices keep their meaning.  Default None = run every step like the reference.
     """
     x = _lib.require_cuda_f32(x, "x")
     x_cond = _lib.require_cuda_f32(x_cond, "x_cond")
@@ -103,7 +106,13 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         t_dev = torch.tensor([float(v) for v in reversed(seq)], dtype=torch.float32).to(dev)
         xs, x0_preds = [x], []
         xt = x
+        n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
+        assert 1 <= n_run <= len(seq), f"stop_at={stop_at} out of range for {len(seq)} steps"
         for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
+            if k >= n_run:
+                x0_preds.append(None)
+                xs.append(None)
+                continue
             at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
             s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
             san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
