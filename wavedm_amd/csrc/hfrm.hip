@@ -9,6 +9,7 @@
 // Activations: NHWC in the model dtype (bf16 or f32), exactly like the UNet.
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ x, T* _
 
 // ---- depthwise 3x3 (pad 1) on 2d channels + SimpleGate x[:, :d] * x[:, d:] + per-block partial sums for the global
 // average pool of the channel attention (arch.py:146-156, 189-192) ---------------------------------------------
-// grid: (pixel blocks, B); a thread owns one 16-byte channel vector of the d output channels and walks PIX pixels
+// grid: (pixel blocks, B, channel blocks); a thread owns one 16-byte channel vector of the d output channels and walks
+// its share of the block's pixels.  All 18 neighbour loads of a pixel are issued together (clamped address + 0/1 weight
+// instead of a branch per tap), so the kernel is bandwidth- and not latency-bound.
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_gate_kernel(const T* __restrict__ x, T* __restrict__ g, int H, int W, int d, const float* __restrict__ wdw,
                                                          const float* __restrict__ bdw, float* __restrict__ pool_partial, int nblocks_per_img,
@@ -113,23 +116,32 @@ __global__ __launch_bounds__(256) void dw3x3_gate_kernel(const T* __restrict__ x
     if (row < rows) {
         const T* xb = x + (long long)b * HW * 2 * d;
         for (int p = p0 + row; p < p1; p += rows) {
-            const int py = p / W, px = p % W;
-            float sa[VEC], sb[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { sa[e] = ba[e]; sb[e] = bb[e]; }
+            const int py = p / W, px = p - py * W;
+            uint4 va[9], vb[9];
+            float m[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int yy = py + dy - 1, xx = px + dx - 1;
-                    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-                    const T* src = xb + ((long long)yy * W + xx) * 2 * d;
-                    float fa[VEC], fb[VEC];
-                    TI<T>::unpack(*(const uint4*)(src + c), fa);
-                    TI<T>::unpack(*(const uint4*)(src + d + c), fb);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) { sa[e] += fa[e] * wa[dy * 3 + dx][e]; sb[e] += fb[e] * wb[dy * 3 + dx][e]; }
+                    const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                    const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                    const T* src = xb + ((long long)yc * W + xc) * 2 * d;
+                    va[dy * 3 + dx] = *(const uint4*)(src + c);
+                    vb[dy * 3 + dx] = *(const uint4*)(src + d + c);
+                    m[dy * 3 + dx] = in ? 1.f : 0.f;
                 }
+            float sa[VEC], sb[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sa[e] = ba[e]; sb[e] = bb[e]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float fa[VEC], fb[VEC];
+                TI<T>::unpack(va[t], fa);
+                TI<T>::unpack(vb[t], fb);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { sa[e] += fa[e] * (wa[t][e] * m[t]); sb[e] += fb[e] * (wb[t][e] * m[t]); }
+            }
             float o[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = sa[e] * sb[e];
@@ -153,14 +165,17 @@ __global__ __launch_bounds__(256) void dw3x3_gate_kernel(const T* __restrict__ x
     }
 }
 
-// pooled[b][c] = sum_blk partial / HW   (fixed order)
-__global__ void pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int B, int nblk_img, int d, float inv_hw) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= B * d) return;
-    const int b = id / d, c = id % d;
+// pooled[b][c] = sum_blk partial / HW   (fixed order: 4 interleaved slices per channel, then the 4 slices)
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int B, int nblk_img, int d, float inv_hw) {
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < nblk_img; ++k) s += partial[((long long)b * nblk_img + k) * d + c];
-    pooled[id] = s * inv_hw;
+    if (c < d)
+        for (int k = sl; k < nblk_img; k += 4) s += partial[((long long)b * nblk_img + k) * d + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && c < d) pooled[b * d + c] = (red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]) * inv_hw;
 }
 
 // g[b][p][c] *= s[b][c]
@@ -229,28 +244,41 @@ __global__ __launch_bounds__(256) void pixel_shuffle_add_kernel(const T* __restr
     }
 }
 
-// conv_in: 3x3 pad 1 on the NCHW f32 image with Cin = 3 (arch.py:210) -> NHWC [M][dim]
-template <typename T>
-__global__ __launch_bounds__(256) void conv3x3_cin3_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int H, int W, int cin, int dim,
+// conv_in: 3x3 pad 1 on the NCHW f32 image with Cin = 3 (arch.py:210) -> NHWC [M][dim].  One thread per pixel: the cin*9 taps are
+// read once (coalesced along x), the [cin*9][dim] weights sit in LDS (broadcast reads), all dim outputs leave as 16-byte stores.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void conv3x3_cin3_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int H, int W, int cin,
                                                            const float* __restrict__ w, const float* __restrict__ bias) {
-    const long long total = (long long)B * H * W * dim;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(id % dim);
-        const long long pix = id / dim;
-        const int px = (int)(pix % W), py = (int)((pix / W) % H);
-        const long long b = pix / ((long long)W * H);
-        float s = bias[co];
-        for (int ci = 0; ci < cin; ++ci)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int yy = py + dy - 1, xx = px + dx - 1;
-                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                        s += x[((b * cin + ci) * H + yy) * W + xx] * w[((co * cin + ci) * 3 + dy) * 3 + dx];
-                }
-        TI<T>::st(y, id, s);
+    constexpr int VEC = TI<T>::VEC;
+    __shared__ float ws[16 * 9 * DIM + DIM];
+    for (int i = threadIdx.x; i < cin * 9 * DIM; i += 256) {
+        const int co = i % DIM, k = i / DIM;                    // k = ci*9 + tap ; w is [co][ci][3][3]
+        ws[i] = w[(long long)co * cin * 9 + k];
     }
+    for (int i = threadIdx.x; i < DIM; i += 256) ws[cin * 9 * DIM + i] = bias[i];
+    __syncthreads();
+    const long long M = (long long)B * H * W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= M) return;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    float acc[DIM];
+#pragma unroll
+    for (int o = 0; o < DIM; ++o) acc[o] = ws[cin * 9 * DIM + o];
+    for (int ci = 0; ci < cin; ++ci) {
+        const float* xp = x + (b * cin + ci) * H * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float v = in ? xp[(long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)] : 0.f;
+            const float* wr = ws + (ci * 9 + t) * DIM;
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) acc[o] += v * wr[o];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DIM; o += VEC) *(uint4*)(y + pix * DIM + o) = TI<T>::pack(acc + o);
 }
 
 // parameter packing helpers -----------------------------------------------------------------------------------
@@ -434,7 +462,8 @@ int wdm_hfrm::run_block(Ctx& c, const BlockD& b, Tens& t, int B, int H, int W) {
     void* n1 = A((size_t)M * d * es);
     void* a2 = A((size_t)M * 2 * d * es);
     void* g = A((size_t)M * d * es);
-    const int ppb = 1024;                                   // pixels per pooling block
+    const int cols_blk = std::min(d / vec, 256);
+    const int ppb = (256 / cols_blk) * 8;                   // pixels per pooling block: 8 per thread
     const int nb = (HW + ppb - 1) / ppb;
     float* part = (float*)A((size_t)B * nb * d * 4);
     float* pooled = (float*)A((size_t)B * d * 4);
@@ -452,7 +481,7 @@ int wdm_hfrm::run_block(Ctx& c, const BlockD& b, Tens& t, int B, int H, int W) {
         const dim3 grid(nb, B, (cols + 255) / 256);
         if (c.dtype == WDM_BF16) hipLaunchKernelGGL(dw3x3_gate_kernel<__bf16>, grid, dim3(256), 0, c.s, (const __bf16*)a2, (__bf16*)g, H, W, d, raw(b.p_dww), raw(b.p_dwb), part, nb, ppb);
         else hipLaunchKernelGGL(dw3x3_gate_kernel<float>, grid, dim3(256), 0, c.s, (const float*)a2, (float*)g, H, W, d, raw(b.p_dww), raw(b.p_dwb), part, nb, ppb);
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3(nblk((long long)B * d, 256)), dim3(256), 0, c.s, part, pooled, B, nb, d, 1.0f / (float)HW);
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((d + 63) / 64, B), dim3(256), 0, c.s, part, pooled, B, nb, d, 1.0f / (float)HW);
         WDM_TRY(k_linear(pooled, B, d, raw(b.p_caw), raw(b.p_cab), d, sc, 0, c.s));
         const long long nvec = M * cols;
         const int gg = nblk(nvec, 256) > 16384 ? 16384 : nblk(nvec, 256);
@@ -483,10 +512,9 @@ int wdm_hfrm::forward(Ctx& c, const float* x, int B, int H, int W, float* yout) 
     void* xin = c.ar->alloc((size_t)B * h * w * cfg.in_channel * es);          // NHWC copy of the input for the final residual
     if (!t.p || !xin) WDM_FAIL(WDM_ENOMEM, "workspace too small (HFRM)");
     if (!c.dry) {
-        const long long total = (long long)B * h * w * d;
-        const int gg = nblk(total, 256) > 16384 ? 16384 : nblk(total, 256);
-        if (c.dtype == WDM_BF16) hipLaunchKernelGGL(conv3x3_cin3_kernel<__bf16>, dim3(gg), dim3(256), 0, c.s, x, (__bf16*)t.p, B, h, w, cfg.in_channel, d, raw(p_cin_w), raw(p_cin_b));
-        else hipLaunchKernelGGL(conv3x3_cin3_kernel<float>, dim3(gg), dim3(256), 0, c.s, x, (float*)t.p, B, h, w, cfg.in_channel, d, raw(p_cin_w), raw(p_cin_b));
+        const int gg = nblk((long long)B * h * w, 256);
+        if (c.dtype == WDM_BF16) hipLaunchKernelGGL((conv3x3_cin3_kernel<__bf16, 32>), dim3(gg), dim3(256), 0, c.s, x, (__bf16*)t.p, B, h, w, cfg.in_channel, raw(p_cin_w), raw(p_cin_b));
+        else hipLaunchKernelGGL((conv3x3_cin3_kernel<float, 32>), dim3(gg), dim3(256), 0, c.s, x, (float*)t.p, B, h, w, cfg.in_channel, raw(p_cin_w), raw(p_cin_b));
         WDM_TRY(k_nchw_to_nhwc(x, xin, B, cfg.in_channel, h, w, c.dtype, c.s));
     }
     std::vector<Tens> encs;
@@ -547,7 +575,7 @@ extern "C" {
 int wdm_hfrm_create(wdm_handle* h, const wdm_hfrm_config* cfg, wdm_hfrm** out) {
     if (!cfg || !out) WDM_FAIL(WDM_EINVAL, "wdm_hfrm_create: null argument");
     if (cfg->n_enc < 1 || cfg->n_enc > 8 || cfg->n_dec != cfg->n_enc) WDM_FAIL(WDM_EINVAL, "wdm_hfrm_create: encoder/decoder level counts must match (1..8)");
-    if (cfg->dim % 32 || cfg->in_channel < 1 || cfg->in_channel > 16) WDM_FAIL(WDM_EINVAL, "wdm_hfrm_create: dim must be a multiple of 32, in_channel <= 16");
+    if (cfg->dim != 32 || cfg->in_channel < 1 || cfg->in_channel > 16) WDM_FAIL(WDM_EINVAL, "wdm_hfrm_create: dim must be 32 (the reference's width), in_channel <= 16");
     if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32) WDM_FAIL(WDM_EINVAL, "wdm_hfrm_create: bad dtype");
     wdm_hfrm* m = new wdm_hfrm();
     m->h = h; m->cfg = *cfg;
