@@ -6,6 +6,7 @@ Public names mirror the reference's `models` package (`models/__init__.py:1-3`) 
 library; the first call that needs it does, and raises if it was not built."""
 from .wavelet import WaveletTransform
 from .unet import DiffusionUNet
+from .arch import HFRM
 from .ddm_wavelet import DenoisingDiffusion_Wavelet, data_transform, inverse_data_transform
 from .restoration import DiffusiveRestoration, torchPSNR
 from .sampling import get_beta_schedule, compute_alpha, overlapping_grid_indices, ddim_sample
