@@ -150,23 +150,63 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 }
 
 // ---- ResnetBlock: GN -> SiLU -> conv3x3 (+temb) -> GN -> SiLU -> conv3x3 -> + (x | nin_shortcut(x)) -------------
+// Two ways to feed a conv its normalised + activated input:
+//  * prologue: the conv kernel applies GN + SiLU to every staged tile (no extra pass over HBM, but every N tile of the
+//    conv repeats the transform: Cout / BN times);
+//  * pass: one elementwise kernel writes act(gn(x)) (and the channel concat) once, the conv runs without prologue.
+// The pass wins where the tensors are small and Cout / BN is large: the 8x8 level (768 channels: 12 N tiles).
+static int gn_pass_max_hw() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("WDM_GN_PASS_HW"); v = e ? atoi(e) : 64; }
+    return v;
+}
+
+// act(gn([x0|x1])) as one dense tensor
+static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, Tens* out) {
+    float *sc, *sh;
+    WDM_TRY(run_gn(c, nw, x0, x1, 0, &sc, &sh));
+    const int C = x0.C + (x1 ? x1->C : 0);
+    WDM_TRY(alloc_tens(c, C, x0.H, x0.W, out));
+    if (!c.dry) {
+        WDM_TRY(k_gn_apply(x0, c.B, sc, sh, C, out->p, C, 0, 1, c.dtype, c.s));
+        if (x1) WDM_TRY(k_gn_apply(*x1, c.B, sc + x0.C, sh + x0.C, C, out->p, C, x0.C, 1, c.dtype, c.s));
+    }
+    c.ar->free(sc); c.ar->free(sh);
+    return WDM_OK;
+}
+
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
     if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
+    const bool pass = x0.H * x0.W <= gn_pass_max_hw();
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
-    WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
-    WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
-    c.ar->free(sc1); c.ar->free(sh1);
-    WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
+    if (pass) {
+        Tens a1;
+        WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
+        free_tens(c, a1);
+    } else {
+        WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
+        c.ar->free(sc1); c.ar->free(sh1);
+    }
     const Tens* res = &x0;
     if (w.has_nin) {
         WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
         res = &sct;
     }
-    WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
-    c.ar->free(sc2); c.ar->free(sh2);
+    if (pass) {
+        Tens a2;
+        WDM_TRY(materialize_gn_silu(c, w.n2, t1, nullptr, &a2));
+        WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        free_tens(c, a2);
+    } else {
+        WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
+        WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        c.ar->free(sc2); c.ar->free(sh2);
+    }
     free_tens(c, t1);
     if (w.has_nin) free_tens(c, sct);
     return WDM_OK;
@@ -184,7 +224,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     WDM_TRY(run_gn(c, w.n, x, nullptr, 0, &sc, &sh));
     Tens hn;
     WDM_TRY(alloc_tens(c, C, x.H, x.W, &hn));
-    if (!c.dry) WDM_TRY(k_gn_apply(x, c.B, sc, sh, hn.p, c.dtype, c.s));
+    if (!c.dry) WDM_TRY(k_gn_apply(x, c.B, sc, sh, C, hn.p, C, 0, 0, c.dtype, c.s));
     c.ar->free(sc); c.ar->free(sh);
 
     Tens qk;

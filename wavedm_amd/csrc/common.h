@@ -121,7 +121,9 @@ size_t gn_stats_bytes(int B, int nslab, int C);
 int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s);
 int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw,
                   float eps, int for_silu_conv, float* scale, float* shift, hipStream_t s);
-int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s);
+// y[b][p][y_choff + c] = act(x*scale + shift); scale/shift rows are sc_ld long (channel concat: pass scale + C0), silu != 0 applies SiLU
+int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int sc_ld, void* y, int y_stride, int y_choff, int silu, int dtype,
+               hipStream_t s);
 int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s);
 int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream_t s);
 // out[n][o] = post( W[o][:] . pre(in[n][:]) + b[o] );  act: 0 none, 1 SiLU on input, 2 SiLU on output

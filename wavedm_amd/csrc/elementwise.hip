@@ -333,10 +333,12 @@ int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const flo
     return WDM_OK;
 }
 
-// GroupNorm apply without activation (AttnBlock.norm, unet.py:169-170): y = x*scale + shift, NHWC dense output
+// GroupNorm apply, optionally followed by SiLU: y = act(x*scale + shift).  Output pixel stride ys / channel offset via the y
+// pointer, scale/shift rows of length sc_ld: two calls materialise the channel concat of two tensors (AttnBlock.norm,
+// unet.py:169-170; the normalised+activated conv input of the 8x8 ResnetBlocks, unet.py:121-123 / 130-133).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int xs, int C, int HW, long long nvec, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, T* __restrict__ y) {
+                                                       const float* __restrict__ shift, int sc_ld, T* __restrict__ y, int ys, int silu) {
     constexpr int VEC = TI<T>::VEC;
     const int cols = C / VEC;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec; id += (long long)gridDim.x * blockDim.x) {
@@ -347,20 +349,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         const uint4 u = *(const uint4*)(x + bp * xs + c);
         float f[VEC];
         TI<T>::unpack(u, f);
-        const float* ps = scale + b * C + c;
-        const float* pf = shift + b * C + c;
+        const float* ps = scale + b * sc_ld + c;
+        const float* pf = shift + b * sc_ld + c;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) f[e] = f[e] * ps[e] + pf[e];
-        *(uint4*)(y + bp * C + c) = TI<T>::pack(f);
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
+        }
+        *(uint4*)(y + bp * ys + c) = TI<T>::pack(f);
     }
 }
-int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, void* y, int dtype, hipStream_t s) {
+int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int sc_ld, void* y, int y_stride, int y_choff, int silu, int dtype,
+               hipStream_t s) {
     const int HW = x.H * x.W;
     const int vec = dtype == WDM_BF16 ? 8 : 4;
     const long long nvec = (long long)B * HW * (x.C / vec);
     const int g = nblocks(nvec, 256) > 16384 ? 16384 : nblocks(nvec, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nvec, scale, shift, (__bf16*)y);
-    else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nvec, scale, shift, (float*)y);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nvec, scale, shift, sc_ld, (__bf16*)y + y_choff, y_stride, silu);
+    else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nvec, scale, shift, sc_ld, (float*)y + y_choff, y_stride, silu);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
