@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c4"],
                     help="c1: BASELINE configs[1] (default, the headline metric); c2: 128x128 patches, batch 256; "
                          "c4: whole 480x720 images, 45 stitched patches each, 50 DDIM steps (informational extra runs)")
+    ap.add_argument("--images-per-call", type=int, default=1, help="c4 only: loader items restored per sampler call (SURVEY.md §8f-2)")
+    ap.add_argument("--max-batch", type=int, default=0, help="UNet call batch cap (default max(batch, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -77,7 +79,8 @@ def main():
     cfg = P.raindrop_wavelet_config(image_size=128 if args.workload == "c2" else 64)
     cfg.device = dev
     a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_rank, image_folder="/tmp/wdm",
-                        test_set="raindrop", grid_r=16, max_batch=max(args.batch, 64))
+                        test_set="raindrop", grid_r=16, max_batch=args.max_batch or max(args.batch, 64),
+                        images_per_call=args.images_per_call)
     t0 = time.time()
     d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=args.dtype)   # HFRM: identity stand-in
     sd = None

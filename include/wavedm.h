@@ -189,6 +189,16 @@ size_t wdm_hfrm_workspace_bytes(const wdm_hfrm* m, int B, int H, int W);
 int wdm_hfrm_forward(wdm_hfrm* m, const float* x, int B, int H, int W, float* y, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- output side of DiffusiveRestoration.restore ---------------------------------
+ * wdm_image_sqdiff: a, b (B,3,H,W) f32 on the device -> sums[B][2] (device, fp64):
+ *   [0] = sum over 3 channels and pixels of (clamp01(a) - clamp01(b))^2   -> torchPSNR, utils/metrics.py:7-11
+ *   [1] = sum over pixels of (Y(a) - Y(b))^2, Y = (24.966 c0 + 128.553 c1 + 65.481 c2 + 16)/255
+ *                                                                          -> calculate_psnr_in_GPU(.., True), :30-51
+ * wdm_to_u8_hwc: (B,C,H,W) f32 -> (B,H,W,C) u8 with torchvision.utils.save_image's rounding
+ *   (x*255 + 0.5, clamp to [0,255], truncate), replacing utils/logging.py:9-12's device->host float copy. */
+int wdm_image_sqdiff(wdm_handle* h, const float* a, const float* b, int B, int H, int W, double* sums, void* stream);
+int wdm_to_u8_hwc(wdm_handle* h, const float* x, int B, int C, int H, int W, uint8_t* y, void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
  * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).

@@ -377,3 +377,55 @@ def hfrm_forward(sd, x, enc_blk_nums=(2, 2, 2, 4), mid_blk_num=6, dec_blk_nums=(
             x = hfrm_block(sd, f"decoders.{i}.{j}", x)
     x = conv(sd, "conv_out", x, padding=1)
     return (x + inp)[:, :, :H, :W]
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY.md §8(f)-2  output metrics / 8-bit conversion / synthetic data directory  (reference: utils/metrics.py,
+# utils/logging.py:9-12, datasets/raindrop.py)
+# ------------------------------------------------------------------------------------------------
+def psnr_torch(gt, out):
+    """utils/metrics.py:7-11 on a (1,3,H,W) pair."""
+    d = out.clamp(0, 1).double() - gt.clamp(0, 1).double()
+    return float(20 * torch.log10(1 / (d ** 2).mean().sqrt()))
+
+
+def psnr_y(gt, out):
+    """utils/metrics.py:30-51 (calculate_psnr_in_GPU(.., test_y_channel=True)); the numpy calculate_psnr(.., True) on the same
+    images scaled to 0..255 is the same number."""
+    wts = torch.tensor([24.966, 128.553, 65.481], dtype=torch.float64)[None, :, None, None]
+    ya = ((gt.double() * wts).sum(dim=1) + 16.0) / 255
+    yb = ((out.double() * wts).sum(dim=1) + 16.0) / 255
+    return float(20. * torch.log10(1. / torch.sqrt(((ya - yb) ** 2).mean())))
+
+
+def to_u8_hwc(img):
+    """torchvision.utils.save_image's quantisation (torchvision is absent from this image: restated from its documented
+    behaviour `mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(uint8)`; parity for this one function is unpinned)."""
+    return img.mul(255).add(0.5).clamp(0, 255).permute(0, 2, 3, 1).to(torch.uint8)
+
+
+def pil_to_tensor(pic):
+    """torchvision.transforms.ToTensor for uint8 PIL images (HWC uint8 -> CHW float /255)."""
+    import numpy as np
+    a = np.asarray(pic)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)
+
+
+def synthetic_raindrop_dir(root, seed=303, sizes=((1000, 640), (300, 500), (720, 480))):
+    """Write <root>/raindrop/raindrop_test/{input/<k>_rain.png, gt/<k>_clean.png}: smooth seeded random images of the given
+    (width, height) sizes.  Returns the sizes.  Used by the golden generator and by the tests (same seed -> same files)."""
+    import os
+    import numpy as np
+    from PIL import Image
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for sub in ("input", "gt"):
+        os.makedirs(os.path.join(root, "raindrop", "raindrop_test", sub), exist_ok=True)
+    for k, (w, h) in enumerate(sizes):
+        base = rng.integers(0, 256, size=(h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+        clean = np.asarray(Image.fromarray(base).resize((w, h), Image.BILINEAR))
+        rain = np.clip(clean.astype(np.int32) + rng.integers(-40, 41, size=clean.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(rain).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
+        Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
+    return [list(s) for s in sizes]

@@ -90,6 +90,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true", help="skip the full-width (156 M) cases")
     ap.add_argument("--only-hfrm", action="store_true", help="regenerate hfrm.npz only")
+    ap.add_argument("--only-io", action="store_true", help="regenerate io.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -129,10 +130,49 @@ def main():
         hf["blk_y"] = yb.numpy()
         np.savez_compressed(out("hfrm.npz"), **hf)
 
+    # ------------------------------------------------------------------ metrics + data loading
+    def golden_io():
+        print("[io]")
+        import random
+        import tempfile
+        import utils as RUT                                        # utils/metrics.py (cv2 / skimage stubbed: unused here)
+        from PIL import Image
+        io = {}
+        gt = seeded((2, 3, 32, 48), 301, "rand")
+        outp = (gt + 0.1 * seeded((2, 3, 32, 48), 302)).clamp(-0.2, 1.2)      # a little outside [0,1]: torchPSNR clamps
+        ref = []
+        for k in range(2):
+            g1, o1 = gt[k:k + 1], outp[k:k + 1]
+            to255 = lambda t: torch.clamp(t[0] * 255, 0, 255).numpy().transpose((1, 2, 0))
+            ref.append([float(RUT.torchPSNR(g1, o1)), float(RUT.calculate_psnr_in_GPU(g1, o1, True)),
+                        float(RUT.calculate_psnr(to255(g1), to255(o1.clamp(0, 1)), True))])
+            assert abs(O.psnr_torch(g1, o1) - ref[-1][0]) < 1e-4 and abs(O.psnr_y(g1, o1) - ref[-1][1]) < 1e-4
+        io["psnr"] = np.array(ref, dtype=np.float64)               # rows: image; cols: torchPSNR, GPU-Y, numpy-Y
+        # eval-path items of the reference dataset class on two synthetic PNG pairs
+        from datasets.raindrop import RainDropDataset
+        tmp = tempfile.mkdtemp(prefix="wdm_golden_ds")
+        sizes = O.synthetic_raindrop_dir(tmp, seed=303)
+        random.seed(61)
+        ds = RainDropDataset(dir=os.path.join(tmp, "raindrop", "raindrop_test"), patch_size=256, n=8, transforms=O.pil_to_tensor,
+                             filelist=None, parse_patches=False)
+        for i in range(len(ds)):
+            x, img_id, total = ds[i]
+            io[f"ds_{img_id}_shape"] = np.array(x.shape, dtype=np.int32)
+            io[f"ds_{img_id}_sub"] = sub(x, 997)
+            io[f"ds_{img_id}_sum"] = np.array(float(x.double().sum()))
+            assert torch.equal(total, x[:3])
+        io["ds_order"] = np.array([re_id for re_id in [ds[i][1] for i in range(len(ds))]])
+        io["ds_sizes"] = np.array(sizes, dtype=np.int32)
+        np.savez_compressed(out("io.npz"), **io)
+
     if args.only_hfrm:
         golden_hfrm()
         return
+    if args.only_io:
+        golden_io()
+        return
     golden_hfrm()
+    golden_io()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")

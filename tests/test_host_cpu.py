@@ -10,6 +10,7 @@ import torch
 
 from wavedm_amd import _lib
 from wavedm_amd import procedural as P
+from oracle import wavedm_oracle as O
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -93,3 +94,29 @@ def test_hfrm_param_table_matches_reference_state_dict_layout():
     assert sum(v.numel() for v in sd.values()) == 15941667
     with pytest.raises(RuntimeError):
         m.pack_weights()              # CPU parameters: no CPU path
+
+
+def test_raindrop_dataset_matches_reference_golden(golden, tmp_path):
+    """datasets/raindrop.py eval path (PIL LANCZOS to 720x480, multiples of 16, ToTensor) -- same items as the reference class
+    produced on the same synthetic PNGs when the golden file was written."""
+    import random
+    from wavedm_amd.datasets import RainDropDataset, eval_size
+    g = golden("io.npz")
+    O.synthetic_raindrop_dir(str(tmp_path), seed=303)
+    random.seed(61)
+    ds = RainDropDataset(dir=str(tmp_path / "raindrop" / "raindrop_test"), patch_size=256, n=8, parse_patches=False)
+    assert len(ds) == 3
+    assert [ds[i][1] for i in range(3)] == [str(v) for v in g["ds_order"]]
+    for i in range(3):
+        x, img_id, total = ds[i]
+        assert tuple(x.shape) == tuple(g[f"ds_{img_id}_shape"])
+        assert np.array_equal(x.flatten()[::997].numpy(), g[f"ds_{img_id}_sub"])
+        assert abs(float(x.double().sum()) - float(g[f"ds_{img_id}_sum"])) < 1e-6 * float(g[f"ds_{img_id}_sum"])
+        assert torch.equal(total, x[:3])
+    assert eval_size(720, 480) == (720, 480) and eval_size(2000, 1000) == (1024, 512) and eval_size(500, 1500) == (352, 1024)
+    assert eval_size(721, 481) == (736, 496)
+    # training path: n crops of patch_size, same crop for input and ground truth
+    random.seed(5)
+    dt = RainDropDataset(dir=str(tmp_path / "raindrop" / "raindrop_test"), patch_size=64, n=4, parse_patches=True)
+    x, img_id, total = dt[0]
+    assert tuple(x.shape) == (4, 6, 64, 64) and tuple(total.shape) == (4, 3, 480, 720)

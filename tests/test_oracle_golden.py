@@ -141,3 +141,15 @@ def test_hfrm_matches_reference_golden(golden):
         assert rel_linf(O.hfrm_forward(sd, x), torch.from_numpy(g["y_" + tag])) <= 1e-5
     xb = seeded((2, 64, 16, 24), 93)
     assert rel_linf(O.hfrm_block(sd, "encoders.1.0", xb), torch.from_numpy(g["blk_y"])) <= 1e-5
+
+
+def test_metrics_match_reference_golden(golden):
+    """oracle PSNR restatements == utils/metrics.py run in the build container."""
+    g = golden("io.npz")
+    gt = seeded((2, 3, 32, 48), 301, "rand")
+    out = (gt + 0.1 * seeded((2, 3, 32, 48), 302)).clamp(-0.2, 1.2)
+    for k in range(2):
+        g1, o1 = gt[k:k + 1], out[k:k + 1]
+        assert abs(O.psnr_torch(g1, o1) - g["psnr"][k, 0]) < 1e-4
+        assert abs(O.psnr_y(g1, o1) - g["psnr"][k, 1]) < 1e-4
+        assert abs(O.psnr_y(g1, o1.clamp(0, 1)) - g["psnr"][k, 2]) < 1e-3     # numpy path: float32 Y on 0..255 data

@@ -10,7 +10,9 @@ from .arch import HFRM
 from .ddm_wavelet import DenoisingDiffusion_Wavelet, data_transform, inverse_data_transform
 from .restoration import DiffusiveRestoration, torchPSNR
 from .sampling import get_beta_schedule, compute_alpha, overlapping_grid_indices, ddim_sample
+from .datasets import RainDrop, RainDropDataset
+from .imageio import AsyncImageWriter
 
 __all__ = ["WaveletTransform", "DiffusionUNet", "DenoisingDiffusion_Wavelet", "DiffusiveRestoration",
            "data_transform", "inverse_data_transform", "torchPSNR", "get_beta_schedule", "compute_alpha",
-           "overlapping_grid_indices", "ddim_sample"]
+           "overlapping_grid_indices", "ddim_sample", "HFRM", "RainDrop", "RainDropDataset", "AsyncImageWriter"]

@@ -1,0 +1,105 @@
+"""Image output off the critical path (reference: `utils/logging.py:9-12`, called ~7x per image from
+`models/restoration.py:158-166` with a synchronous float D2H copy + PNG encode each).
+
+`AsyncImageWriter.save(img, path)`: quantise on the GPU (wdm_to_u8_hwc: one byte per sample crosses PCIe instead of four),
+copy to a pinned buffer on a side stream, hand the buffer to a worker thread that waits for the copy's event and encodes
+the PNG with PIL.  The sampler's stream never waits for any of it.  `metrics(gt, out)` returns the three PSNRs the
+reference prints, from one device reduction (wdm_image_sqdiff)."""
+from __future__ import annotations
+
+import math
+import os
+import queue
+import threading
+
+import torch
+
+from . import _lib
+
+
+def to_u8_hwc(img: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) or (C,H,W) f32 on the GPU -> (B,H,W,C) uint8 with torchvision.utils.save_image's rounding."""
+    img = _lib.require_cuda_f32(img if img.dim() == 4 else img[None], "to_u8_hwc input")
+    B, C, H, W = img.shape
+    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.lib().wdm_to_u8_hwc(_lib.handle(img.device.index or 0), _lib.ptr(img), B, C, H, W, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def sqdiff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Per-image [sum (clamp a - clamp b)^2 over RGB, sum (Y(a)-Y(b))^2] in fp64 on the device: (B,2)."""
+    a, b = _lib.require_cuda_f32(a, "metrics input"), _lib.require_cuda_f32(b, "metrics input")
+    if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 3:
+        raise ValueError(f"metrics: expected two (B,3,H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+    B, _, H, W = a.shape
+    out = torch.empty(B, 2, dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().wdm_image_sqdiff(_lib.handle(a.device.index or 0), _lib.ptr(a), _lib.ptr(b), B, H, W, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def psnr_from_sums(sums, H, W):
+    """-> list of (psnr_torch, psnr_y) per image; utils/metrics.py:7-11 and :43-51 / :53-77 (the numpy Y-PSNR on 0..255 data is the
+    same number as the GPU one: the 255s cancel)."""
+    res = []
+    for s_rgb, s_y in sums.tolist():
+        mse_rgb, mse_y = s_rgb / (3.0 * H * W), s_y / (H * W)
+        res.append((20.0 * math.log10(1.0 / math.sqrt(mse_rgb)) if mse_rgb > 0 else float("inf"),
+                    20.0 * math.log10(1.0 / math.sqrt(mse_y)) if mse_y > 0 else float("inf")))
+    return res
+
+
+class AsyncImageWriter:
+    def __init__(self, max_pending: int = 64):
+        self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
+        self._thread = threading.Thread(target=self._run, name="wavedm-png-writer", daemon=True)
+        self._stream = None
+        self._errors = []
+        self._thread.start()
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            item = self._q.get()
+            try:
+                if item is None:
+                    return
+                host, event, path = item
+                event.synchronize()
+                os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+                arr = host.numpy()
+                Image.fromarray(arr[..., 0] if arr.shape[-1] == 1 else arr).save(path)
+            except Exception as e:                      # surfaced by flush()
+                self._errors.append(e)
+            finally:
+                self._q.task_done()
+
+    def save(self, img: torch.Tensor, path: str):
+        """img: (1,C,H,W) or (C,H,W) f32 in [0,1] on the GPU (utils/logging.save_image's first image semantics)."""
+        if img.dim() == 4:
+            img = img[:1]
+        u8 = to_u8_hwc(img)[0]
+        dev = u8.device
+        if self._stream is None or self._stream.device != dev:
+            self._stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            host.copy_(u8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        u8.record_stream(self._stream)
+        self._q.put((host, ev, path))
+
+    def flush(self):
+        self._q.join()
+        if self._errors:
+            e, self._errors = self._errors[0], []
+            raise e
+
+    def close(self):
+        self.flush()
+        self._q.put(None)
+        self._thread.join(timeout=10)

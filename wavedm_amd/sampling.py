@@ -62,8 +62,10 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
 
     x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
     corners: None -> every image is one p x p patch at (0,0) (p == H == W; the batched 64x64 case),
-             or a list of (hi, wi) applied to image 0 (the reference's stitched single-image case),
-             or a list of (img, hi, wi).
+             or a list of (hi, wi) applied to EVERY image of the batch, like the reference's crops
+             `x_cond[:, :, hi:hi+p, wi:wi+p]` (ddm_wavelet.py:467-478) -- image-major patch order, so each image's
+             overlap sums run in the same order as when it is restored alone,
+             or an explicit list of (img, hi, wi).
     keep: "all" -> (xs, x0_preds) lists as the reference returns; or a set of negative indices into
           x0_preds / xs to retain, e.g. {-5, -1} (saves nothing but list bookkeeping).
     stop_at: opt-in early stop: a negative index k means "x0_preds[k] is all the caller needs", so the
@@ -86,7 +88,10 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             n, patches, pptr = nimg, None, None
         else:
             p = int(p_size)
-            tri = [(0, int(c[0]), int(c[1])) if len(c) == 2 else tuple(int(v) for v in c) for c in corners]
+            if all(len(c) == 2 for c in corners):
+                tri = [(im, int(c[0]), int(c[1])) for im in range(nimg) for c in corners]
+            else:
+                tri = [tuple(int(v) for v in c) for c in corners]
             for (im, hi, wi) in tri:
                 if not (0 <= im < nimg and 0 <= hi and hi + p <= H and 0 <= wi and wi + p <= W):
                     raise ValueError(f"patch {(im, hi, wi)} of size {p} outside the {nimg}x{H}x{W} image")
