@@ -60,10 +60,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("WAVEDM_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only to smoke-test the N > 1 code path on one GPU
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     torch.set_grad_enabled(False)
 
     from types import SimpleNamespace
@@ -78,7 +83,7 @@ def main():
         args.batch = 1 if args.batch == 64 else args.batch
     cfg = P.raindrop_wavelet_config(image_size=128 if args.workload == "c2" else 64)
     cfg.device = dev
-    a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_rank, image_folder="/tmp/wdm",
+    a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_dev, image_folder="/tmp/wdm",
                         test_set="raindrop", grid_r=16, max_batch=args.max_batch or max(args.batch, 64),
                         images_per_call=args.images_per_call)
     t0 = time.time()
