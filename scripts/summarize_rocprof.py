@@ -23,6 +23,10 @@ def short(name: str) -> str:
             mode = {0: "3x3s1", 1: "3x3s2", 2: "3x3ups", 3: "1x1"}[a[0]]
             ty = "bf16" if m.group(1) == "DF16b" else "f32"
             return f"conv_{mode}_t{a[1]}x{a[2]}x{a[3]}_bn{16 * a[7] * a[5]}_{ty}"
+    m = re.search(r"conv_dma_kernelI((?:Li\d+E)+)", name)
+    if m:
+        a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        return f"convdma_3x3s1_t16x16x1_bn128w{a[0] * a[1]}_bf16"
     m = re.search(r"conv_gemm_kernelI((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]

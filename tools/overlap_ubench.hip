@@ -58,11 +58,16 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
 }
 
 template <int MODE, int KIND, int R> void run(const char* name, unsigned long long* d, float* sink) {
-    const int iters = 2000;
+    const int iters = 200000;
     hipLaunchKernelGGL((k<MODE, KIND, R>), dim3(256), dim3(512), 0, 0, d, sink, iters);
     CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL((k<MODE, KIND, R>), dim3(256), dim3(512), 0, 0, d, sink, iters);
+    CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (MODE == 0) printf("   [MFMA-only kernel: %.3f ms -> %.0f TFLOP/s sustained, %.2f ticks/ns]\n", ms, 256.0 * 8 * iters * 8 * 16384.0 / (ms * 1e-3) / 1e12, 0.0);
     unsigned long long h[8];
     CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
     printf("%-34s per 8-MFMA-group (or 8*R VALU): wave0 %.1f  wave4 %.1f ticks\n", name, (double)h[0] / iters, (double)h[4] / iters);

@@ -2,4 +2,5 @@
 #define WDM_LAUNCH_NAME launch_conv_bf16
 #define WDM_HAS_GEMM 1
 #include "conv_gemm_kernel.h"
+#include "conv_dma_kernel.h"
 #include "conv_dispatch.inc"
