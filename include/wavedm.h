@@ -85,6 +85,15 @@ int wdm_ddim_update(wdm_handle* h, const float* eps, const int32_t* patches, int
                     int nimg, int H, int W, float sqrt_1m_at, float sqrt_at, float sqrt_at_next, float c2,
                     float* x0_out, float* x_next_out, void* stream);
 
+/* Patch-sharded single image (no reference counterpart -- its eval is single-GPU): every rank runs the UNet
+ * on ITS patches only.  wdm_patch_accumulate writes the rank's partial sums (NIMG*3*H*W floats) followed by its partial overlap
+ * counts (same size) into acc_cnt, the caller all-reduces (sum) that ONE buffer over RCCL, and wdm_ddim_from_sums divides and
+ * applies the DDIM update of wdm_ddim_update on every rank.  n = 0 writes zeros. */
+int wdm_patch_accumulate(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W,
+                         float* acc_cnt, void* stream);
+int wdm_ddim_from_sums(wdm_handle* h, const float* acc_cnt, const float* x_t, int nimg, int H, int W, float sqrt_1m_at,
+                       float sqrt_at, float sqrt_at_next, float c2, float* x0_out, float* x_next_out, void* stream);
+
 /* NCHW f32 (B,C,H,W) -> NHWC dtype (B,H,W,C) and back (used by the drop-in model(x, t) call). */
 int wdm_nchw_to_nhwc(wdm_handle* h, const float* src, void* dst, int B, int C, int H, int W, int dtype,
                      void* stream);

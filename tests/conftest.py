@@ -24,6 +24,7 @@ _limit_cpu_threads()
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor:DeprecationWarning")     # torch's own DataLoader pin_memory path
 
 
 @pytest.fixture(scope="session")

@@ -57,6 +57,19 @@ int wdm_ddim_update(wdm_handle* h, const float* eps, const int32_t* patches, int
     if (!h || !eps || !x_t || !x0_out || !x_next_out) WDM_FAIL(WDM_EINVAL, "wdm_ddim_update: null argument");
     return k_ddim_update(eps, patches, n, p, x_t, nimg, H, W, sqrt_1m_at, sqrt_at, sqrt_at_next, c2, x0_out, x_next_out, (hipStream_t)stream);
 }
+int wdm_patch_accumulate(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W, float* acc_cnt, void* stream) {
+    if (!h || !acc_cnt || (n > 0 && (!eps || !patches))) WDM_FAIL(WDM_EINVAL, "wdm_patch_accumulate: null argument");
+    if (n == 0) {      // a rank that owns no patch of this step contributes zeros
+        WDM_HIP(hipMemsetAsync(acc_cnt, 0, (size_t)nimg * 3 * H * W * 2 * sizeof(float), (hipStream_t)stream));
+        return WDM_OK;
+    }
+    return k_patch_accumulate(eps, patches, n, p, nimg, H, W, acc_cnt, (hipStream_t)stream);
+}
+int wdm_ddim_from_sums(wdm_handle* h, const float* acc_cnt, const float* x_t, int nimg, int H, int W, float sqrt_1m_at, float sqrt_at, float sqrt_at_next,
+                       float c2, float* x0_out, float* x_next_out, void* stream) {
+    if (!h || !acc_cnt || !x_t || !x0_out || !x_next_out) WDM_FAIL(WDM_EINVAL, "wdm_ddim_from_sums: null argument");
+    return k_ddim_from_sums(acc_cnt, x_t, nimg, H, W, sqrt_1m_at, sqrt_at, sqrt_at_next, c2, x0_out, x_next_out, (hipStream_t)stream);
+}
 int wdm_nchw_to_nhwc(wdm_handle* h, const float* src, void* dst, int B, int C, int H, int W, int dtype, void* stream) {
     if (!h || !src || !dst) WDM_FAIL(WDM_EINVAL, "wdm_nchw_to_nhwc: null argument");
     return k_nchw_to_nhwc(src, dst, B, C, H, W, dtype, (hipStream_t)stream);

@@ -111,6 +111,9 @@ int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patc
                     int c_total, int c_off, int dtype, hipStream_t s);
 int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W,
                   float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s);
+int k_patch_accumulate(const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W, float* acc_cnt, hipStream_t s);
+int k_ddim_from_sums(const float* acc_cnt, const float* x_t, int nimg, int H, int W, float s1m, float sa, float san, float c2, float* x0,
+                     float* xn, hipStream_t s);
 int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
 int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype, hipStream_t s);
 // GroupNorm(32, eps): partial statistics float4[B][nslab][C] = (pivot, sum(x-K), sum((x-K)^2), n) and their finalisation

@@ -167,6 +167,55 @@ int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const 
     return WDM_OK;
 }
 
+// ---- patch-sharded single image: each rank owns a subset of the patches.  patch_accumulate writes the rank's
+// partial sums [0 .. nimg*3*H*W) and partial counts [nimg*3*H*W ..) into ONE buffer (one all-reduce per step); ddim_from_sums
+// divides the reduced sums by the reduced counts and applies the same DDIM update as ddim_update_kernel.
+__global__ __launch_bounds__(256) void patch_accumulate_kernel(const float* __restrict__ eps, const int32_t* __restrict__ patches, int n, int p, int nimg, int H,
+                                                               int W, float* __restrict__ acc_cnt) {
+    const long long total = (long long)nimg * 3 * H * W;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(id % W);
+        const int yy = (int)((id / W) % H);
+        const int c = (int)((id / ((long long)W * H)) % 3);
+        const int img = (int)(id / ((long long)W * H * 3));
+        float acc = 0.f, cnt = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const int pi = patches[3 * k], hi = patches[3 * k + 1], wi = patches[3 * k + 2];
+            if (pi == img && (unsigned)(yy - hi) < (unsigned)p && (unsigned)(xx - wi) < (unsigned)p) {
+                acc += eps[(((long long)k * 3 + c) * p + (yy - hi)) * p + (xx - wi)];
+                cnt += 1.f;
+            }
+        }
+        acc_cnt[id] = acc;
+        acc_cnt[total + id] = cnt;
+    }
+}
+__global__ __launch_bounds__(256) void ddim_from_sums_kernel(const float* __restrict__ acc_cnt, const float* __restrict__ x_t, long long total, float s1m, float sa,
+                                                             float san, float c2, float* __restrict__ x0o, float* __restrict__ xno) {
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const float et = acc_cnt[id] / acc_cnt[total + id];
+        const float x0 = (x_t[id] - et * s1m) / sa;
+        x0o[id] = x0;
+        xno[id] = san * x0 + c2 * et;
+    }
+}
+int k_patch_accumulate(const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W, float* acc_cnt, hipStream_t s) {
+    if (n < 0 || nimg <= 0 || !patches) WDM_FAIL(WDM_EINVAL, "patch_accumulate: bad arguments");
+    const long long total = (long long)nimg * 3 * H * W;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    hipLaunchKernelGGL(patch_accumulate_kernel, dim3(g), dim3(256), 0, s, eps, patches, n, p, nimg, H, W, acc_cnt);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+int k_ddim_from_sums(const float* acc_cnt, const float* x_t, int nimg, int H, int W, float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s) {
+    const long long total = (long long)nimg * 3 * H * W;
+    if (total <= 0) WDM_FAIL(WDM_EINVAL, "ddim_from_sums: empty image");
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    hipLaunchKernelGGL(ddim_from_sums_kernel, dim3(g), dim3(256), 0, s, acc_cnt, x_t, total, s1m, sa, san, c2, x0, xn);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
 // =================================================================================================
 // layout conversion at the drop-in model(x, t) boundary
 // =================================================================================================

@@ -41,6 +41,7 @@ class DenoisingDiffusion_Wavelet(object):
         if self.device.type != "cuda":
             raise RuntimeError("wavedm_amd runs on MI355X only: config.device must be a cuda (ROCm) device")
         self.verbose = verbose
+        self.patch_group = None     # set to a process group (or True) to shard the PATCHES of each image over the ranks
 
         self.wavelet_dec = WaveletTransform(scale=2, dec=True)
         self.wavelet_rec = WaveletTransform(scale=2, dec=False)
@@ -131,8 +132,12 @@ class DenoisingDiffusion_Wavelet(object):
         if not self.config.data.begin_from_noise:                              # ddm_wavelet.py:445-447
             a = (1 - b).cumprod(dim=0)[self.num_timesteps - 1]
             x = x_cond[:, :x.shape[1]] * a.sqrt() + x * (1.0 - a).sqrt()
+        grp = getattr(self, "patch_group", None)
+        if grp is not None:                                                    # patch-sharded latency mode: identical start noise on every rank
+            import torch.distributed as dist
+            dist.broadcast(x, src=0, group=None if grp is True else grp)
         xs, x0_preds = sampling.ddim_sample(model, x, x_cond, x_other, list(seq), b, corners=corners, p_size=p_size,
-                                            max_batch=getattr(self.args, "max_batch", 64))
+                                            max_batch=getattr(self.args, "max_batch", 64), patch_group=grp)
         if self.verbose:
             for i_t, x0, xn in zip(reversed(list(seq)), x0_preds, xs[1:]):
                 print(f"t:{i_t} x0 pred:{x0.mean().item()} x next:{xn.mean().item()}")

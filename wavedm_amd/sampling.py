@@ -57,7 +57,8 @@ def overlapping_grid_indices(h, w, output_size, r=None):
     return h_list, w_list
 
 
-def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None):
+def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None,
+                patch_group=None):
     """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
 
     x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
@@ -71,6 +72,11 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
     stop_at: opt-in early stop: a negative index k means "x0_preds[k] is all the caller needs", so the
           |k|-1 steps after it -- which the reference computes and discards (restoration.py:108 uses [-5]) -- are skipped;
           the lists are padded with None so indices keep their meaning.  Default None = run every step like the reference.
+    patch_group: a torch.distributed process group (or True for the default group) = patch-sharded latency mode
+          (SURVEY.md §8e-ii): the patch list is split contiguously over the ranks, each rank runs the UNet on its patches,
+          and ONE all-reduce(sum) per step (RCCL) combines partial sums and overlap counts before the DDIM update, which every
+          rank then applies identically.  All ranks must pass the same x / x_cond / x_other.  The fp32 sum order differs from
+          the sequential scatter by at most the association of the per-rank partial sums.
     """
     x = _lib.require_cuda_f32(x, "x")
     x_cond = _lib.require_cuda_f32(x_cond, "x_cond")
@@ -95,15 +101,27 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             for (im, hi, wi) in tri:
                 if not (0 <= im < nimg and 0 <= hi and hi + p <= H and 0 <= wi and wi + p <= W):
                     raise ValueError(f"patch {(im, hi, wi)} of size {p} outside the {nimg}x{H}x{W} image")
+            sharded = patch_group is not None
+            if sharded:
+                import torch.distributed as dist
+                from .parallel import shard_range
+                grp = None if patch_group is True else patch_group
+                lo, hi = shard_range(len(tri), dist.get_rank(grp), dist.get_world_size(grp))
+                tri = tri[lo:hi]
             n = len(tri)
-            patches = torch.tensor(tri, dtype=torch.int32).to(dev)
+            patches = torch.tensor(tri if tri else [(0, 0, 0)], dtype=torch.int32).to(dev)
             pptr = _lib.ptr(patches)
         assert p == unet.resolution, "patch size must equal config.data.image_size (unet.py:351)"
+        sharded = corners is not None and patch_group is not None
+        if patch_group is not None and corners is None:
+            raise ValueError("patch_group needs a corner list: independent crops shard by image (parallel.restore_sharded)")
         st = _lib.stream_ptr()
-        x96 = torch.empty(n, p, p, cin, device=dev, dtype=unet._torch_dtype)
-        _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
-        _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
-        eps = torch.empty(n, pc, p, p, device=dev, dtype=torch.float32)
+        x96 = torch.empty(max(n, 1), p, p, cin, device=dev, dtype=unet._torch_dtype)
+        if n:
+            _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
+            _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
+        eps = torch.empty(max(n, 1), pc, p, p, device=dev, dtype=torch.float32)
+        acc_cnt = torch.empty(2 * x.numel(), device=dev, dtype=torch.float32) if sharded else None
 
         seq = list(seq)
         seq_next = [-1] + seq[:-1]
@@ -121,13 +139,19 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
             s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
             san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
-            _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
+            if n:
+                _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
             for i in range(0, n, max_batch):
                 unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch])
             x0 = torch.empty_like(x)
             xn = torch.empty_like(x)
-            _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
-                                         _lib.ptr(x0), _lib.ptr(xn), st))
+            if sharded:
+                _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
+                dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
+                _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
+            else:
+                _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
+                                             _lib.ptr(x0), _lib.ptr(xn), st))
             x0_preds.append(x0)
             xs.append(xn)
             xt = xn
