@@ -191,3 +191,32 @@ def test_config4_fullres_stitch(dtype):
         assert rel_linf(outs[0].cpu(), want) <= 1e-3
     else:
         assert float((outs[0].cpu() - want).abs().mean()) <= 2e-2
+
+
+def test_checkpoint_formats(tmp_path):
+    """--resume with the reference's checkpoint dict (utils/logging.py:15-18, ddm_wavelet.py:180-190, :282-292): DDP-prefixed or
+    plain state_dict keys, the EMA shadow dict, strict key checking."""
+    from types import SimpleNamespace
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    from oracle import wavedm_oracle as O
+    cfg = P.reduced_config()
+    cfg.device = torch.device("cuda", 0)
+    sd = P.procedural_state_dict(cfg, seed=61)
+    ema = {k: v * 1.25 for k, v in sd.items()}
+    path = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"epoch": 3, "step": 77, "state_dict": {"module." + k: v for k, v in sd.items()}, "optimizer": {}, "ema_helper": ema,
+                "params": None, "config": None}, path)
+    args = SimpleNamespace(resume=path, sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
+    assert (d.start_epoch, d.step) == (3, 77)
+    x96 = seeded((1, 96, 16, 16), 40).cuda()
+    t = torch.tensor([500.0])
+    assert rel_linf(d.model(x96, t).cpu(), O.unet_forward(sd, cfg, x96.cpu(), t)) <= TOL["f32"]
+    d.load_ddm_ckpt(path, ema=True)                                                  # EMAHelper.ema: the shadow weights replace the parameters
+    assert rel_linf(d.model(x96, t).cpu(), O.unet_forward(ema, cfg, x96.cpu(), t)) <= TOL["f32"]
+    bad = dict(sd)
+    bad.pop("conv_out.bias")
+    torch.save({"epoch": 0, "step": 0, "state_dict": bad}, path)
+    with pytest.raises(RuntimeError):
+        d.load_ddm_ckpt(path)                                                        # strict=True like the reference

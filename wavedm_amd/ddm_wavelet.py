@@ -87,7 +87,10 @@ class DenoisingDiffusion_Wavelet(object):
 
     # ---- checkpoint (utils/logging.py:21-29 + ddm_wavelet.py:180-190) -------------------------
     def load_ddm_ckpt(self, load_path, ema=False):
-        ckpt = torch.load(load_path, map_location="cpu", weights_only=False)
+        try:        # zip-format checkpoints are memory-mapped: tensors are paged in one by one while they are copied to the GPU,
+            ckpt = torch.load(load_path, map_location="cpu", weights_only=False, mmap=True)     # no 626 MB fp32 staging copy on the host
+        except (RuntimeError, ValueError):                                                      # legacy (non-zip) files cannot be mapped
+            ckpt = torch.load(load_path, map_location="cpu", weights_only=False)
         self.start_epoch = ckpt.get("epoch", 0)
         self.step = ckpt.get("step", 0)
         sd = ckpt["state_dict"]
