@@ -82,7 +82,8 @@ int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
 // ---- one fused convolution ---------------------------------------------------------------------
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
-             int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats) {
+             int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats, const ConvW* shortcut,
+             const Tens* sx0, const Tens* sx1) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -108,6 +109,13 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
     a.res = res ? res->p : nullptr; a.res_s = res ? res->xs : 0;
     a.y = y; a.y_mode = y_mode; a.y_s = w.cout;
+    if (shortcut) {      // 1x1 conv over [sx0 | sx1] accumulated into the same tile
+        a.sx0 = sx0->p; a.sx1 = sx1 ? sx1->p : nullptr;
+        a.sC0 = sx0->C; a.sC1 = sx1 ? sx1->C : 0; a.sxs0 = sx0->xs; a.sxs1 = sx1 ? sx1->xs : 0;
+        a.sw = shortcut->w; a.sw_row_stride = shortcut->cin; a.sw_rows = shortcut->rows_pad;
+        a.sw_bytes = (unsigned)((size_t)shortcut->rows_pad * shortcut->cin * dsize(c.dtype));
+        a.sbias = shortcut->b;
+    }
     if (want_stats && !y_ext && w.cout % 8 == 0) {
         // the producing conv also emits the GroupNorm partial statistics of its output (no extra pass over HBM)
         int nslab = 0;
@@ -155,6 +163,11 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 //    conv repeats the transform: Cout / BN times);
 //  * pass: one elementwise kernel writes act(gn(x)) (and the channel concat) once, the conv runs without prologue.
 // The pass wins where the tensors are small and Cout / BN is large: the 8x8 level (768 channels: 12 N tiles).
+static bool fuse_shortcut_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("WDM_FUSE_NIN"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 static int gn_pass_max_hw() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("WDM_GN_PASS_HW"); v = e ? atoi(e) : 64; }
@@ -192,8 +205,12 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
         c.ar->free(sc1); c.ar->free(sh1);
     }
+    // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
+    // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
+    const bool fuse_nin = w.has_nin && !pass && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
+                          conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
-    if (w.has_nin) {
+    if (w.has_nin && !fuse_nin) {
         WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
         res = &sct;
     }
@@ -204,11 +221,12 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         free_tens(c, a2);
     } else {
         WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
-        WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
         c.ar->free(sc2); c.ar->free(sh2);
     }
     free_tens(c, t1);
-    if (w.has_nin) free_tens(c, sct);
+    if (w.has_nin && !fuse_nin) free_tens(c, sct);
     return WDM_OK;
 }
 

@@ -142,6 +142,11 @@ bool prof_enabled();
 void prof_begin(hipStream_t s, const char* kernel, double flops, double bytes);
 void prof_end(hipStream_t s);
 
+// shapes whose 3x3 conv can also accumulate a 1x1 shortcut over [sC0 | sC1] channels (conv_dma_kernel.h; bf16 only)
+inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int sC1) {
+    return H % 16 == 0 && W % 16 == 0 && cout >= 128 && cin % 32 == 0 && cin <= 2048 && sC0 % 64 == 0 && (sC0 + sC1) % 64 == 0;
+}
+
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 
@@ -149,7 +154,7 @@ int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 // want_stats: also emit the GroupNorm partial statistics of the output (out->stats) from the conv epilogue
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
-             bool want_stats = false);
+             bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr);
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
 int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);

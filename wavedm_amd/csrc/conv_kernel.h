@@ -83,6 +83,15 @@ struct ConvArgs {
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
                            //    (plain GEMMs over M rows that do not fill the last row of the 16-wide pixel grid)
+    // optional second contraction accumulated into the same output tile (conv_dma_kernel.h only): the ResnetBlock's 1x1
+    // nin_shortcut over the block input [sx0 | sx1] (unet.py:134-137), so that `x_shortcut + h` is one accumulator
+    const void* sx0;       // nullptr: none
+    const void* sx1;
+    int sC0, sC1, sxs0, sxs1;
+    const void* sw;        // [row][sC0 + sC1] model dtype
+    int sw_row_stride, sw_rows;
+    unsigned sx0_bytes, sx1_bytes, sw_bytes;
+    const float* sbias;    // [Cout] added like bias
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -208,7 +217,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
             const int n = ncol0 + c8;
             float bias8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+            for (int e = 0; e < 8; ++e)
+                bias8[e] = ((a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f) + ((a.sbias != nullptr && n + e < a.Cout) ? a.sbias[n + e] : 0.f);
             // GroupNorm partial statistics of the values as stored (optional): the final values go back into the LDS tile
             // and a column pass (lane = channel) sums them -- no cross-lane shuffles
             const bool do_stats = a.stats != nullptr;
@@ -319,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 for (int c = 0; c < ECOLS; ++c) {
                     const int n = ncol0 + c;
                     if (n >= a.Cout) break;
-                    float v = ep[rloc * ESTR + c] * a.alpha + (a.bias != nullptr ? a.bias[n] : 0.f);
+                    float v = ep[rloc * ESTR + c] * a.alpha + (a.bias != nullptr ? a.bias[n] : 0.f) + (a.sbias != nullptr ? a.sbias[n] : 0.f);
                     if (a.temb != nullptr) v += a.temb[(long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n];
                     if (a.res != nullptr) v += TI<T>::ld(a.res, opix * a.res_s + n);
                     if (a.y_mode == Y_NHWC) TI<T>::st(a.y, opix * a.y_s + n, v);
