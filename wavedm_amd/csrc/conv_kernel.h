@@ -200,7 +200,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
     const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
 #pragma unroll
     for (int jp = 0; jp < WN; jp += NJ) {
-        __syncthreads();                              // main loop / previous pass finished with this LDS
+        // The fp32 tile is private to the wave, and the LDS executes one wave's instructions in order: only the hand-over from the
+        // main loop (other waves may still read the operand images this tile overlays) needs the workgroup barrier.
+        if (jp == 0) __syncthreads();
+        else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         if (active)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
@@ -209,7 +212,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (!active) continue;
         const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
         if (vec_ok) {
