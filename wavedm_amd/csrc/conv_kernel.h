@@ -198,6 +198,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
     constexpr int RPI = 64 / LPR;                     // rows per iteration
     float* ep = (float*)smem + wave * (EROWS * ESTR);
     const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
+    // additive per-channel terms of BOTH passes, fetched up front as 16-byte loads so that their latency overlaps the LDS
+    // transposes instead of opening every pass: bias + shortcut bias + temb.  A wave tile lies inside one image
+    // (static_assert), so temb's row is a per-wave constant.
+    constexpr int NPASS = (WN + NJ - 1) / NJ;
+    static_assert((TH * TW) % EROWS == 0 || EROWS % (TH * TW) == 0, "wave tile vs image geometry");
+    float add8[NPASS][8];
+    if (vec_ok && active) {
+        const int img_w = img0 + (wave_m * EROWS) / (TH * TW);
+        const long long trow = (a.temb != nullptr && a.temb_per_image) ? (img_w < a.B ? img_w : a.B - 1) : 0;
+        constexpr bool ONE_IMG = (TH * TW) % EROWS == 0;         // else (8x8 tiles, 128-row wave tiles) temb stays in the row loop
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int n = n0 + (wave_n * WN + ps * NJ) * 16 + (lane % LPR) * 8;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (n < a.Cout) {          // Cout % 8 == 0 and n % 8 == 0: all eight channels exist
+                if (a.bias != nullptr) { b0 = *(const float4*)(a.bias + n); b1 = *(const float4*)(a.bias + n + 4); }
+                if (a.sbias != nullptr) {
+                    const float4 c0 = *(const float4*)(a.sbias + n), c1 = *(const float4*)(a.sbias + n + 4);
+                    b0.x += c0.x; b0.y += c0.y; b0.z += c0.z; b0.w += c0.w; b1.x += c1.x; b1.y += c1.y; b1.z += c1.z; b1.w += c1.w;
+                }
+                if (ONE_IMG && a.temb != nullptr) {
+                    const float* tp = a.temb + trow * a.temb_ld + n;
+                    const float4 c0 = *(const float4*)tp, c1 = *(const float4*)(tp + 4);
+                    b0.x += c0.x; b0.y += c0.y; b0.z += c0.z; b0.w += c0.w; b1.x += c1.x; b1.y += c1.y; b1.z += c1.z; b1.w += c1.w;
+                }
+            }
+            add8[ps][0] = b0.x; add8[ps][1] = b0.y; add8[ps][2] = b0.z; add8[ps][3] = b0.w;
+            add8[ps][4] = b1.x; add8[ps][5] = b1.y; add8[ps][6] = b1.z; add8[ps][7] = b1.w;
+        }
+    }
+    constexpr bool TEMB_IN_ADD = (TH * TW) % EROWS == 0;
 #pragma unroll
     for (int jp = 0; jp < WN; jp += NJ) {
         // The fp32 tile is private to the wave, and the LDS executes one wave's instructions in order: only the hand-over from the
@@ -221,8 +252,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
             const int n = ncol0 + c8;
             float bias8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                bias8[e] = ((a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f) + ((a.sbias != nullptr && n + e < a.Cout) ? a.sbias[n + e] : 0.f);
+            for (int e = 0; e < 8; ++e) bias8[e] = add8[jp / NJ][e];
             // GroupNorm partial statistics of the values as stored (optional): the final values go back into the LDS tile
             // and a column pass (lane = channel) sums them -- no cross-lane shuffles
             const bool do_stats = a.stats != nullptr;
@@ -242,7 +272,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
                 const long long opix = ((long long)(valid ? img_g : 0) * a.Hout + oy) * a.Wout + ox;
                 if (valid) {
-                    if (a.temb != nullptr) {
+                    if (!TEMB_IN_ADD && a.temb != nullptr) {
                         const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
                         const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
                         v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
