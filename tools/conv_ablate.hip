@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "conv_ws_kernel.h"
+#include "conv_kernel.h"
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -34,11 +34,7 @@ int main(int argc, char** argv) {
     unsigned long long* ts; CK(hipMalloc(&ts, 1 << 20)); CK(hipMemset(ts, 0, 1 << 20));
     a.temb = (const float*)ts; a.temb_ld = 0; a.temb_per_image = 0;   // the instrumented kernel writes timestamps here
 #endif
-#ifdef WDM_WS
-    using C = ConvWsCfg<__bf16, 16, 16, 1, 4, 1, 4, 4>;
-    auto kern = conv_ws_kernel<__bf16, 16, 16, 1, 4, 1, 4, 4>;
-    const int nthr = C::NTHREADS;
-#elif defined(WDM_BN128)
+#if defined(WDM_BN128)
     using C = ConvCfg<__bf16, MODE_S1, 16, 16, 1, 4, 2, 4, 4>;
     auto kern = conv_kernel<__bf16, MODE_S1, 16, 16, 1, 4, 2, 4, 4>;
     const int nthr = 512;
@@ -60,7 +56,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * B * H * H * Cout * 9.0 * Cin;
-    printf("%s gn=%d ABL=%d B=%d H=%d %d->%d pro=%d grid=%d lds=%d : %.1f us  %.1f TFLOP/s\n", nthr == 768 ? "WS" : nthr == 512 ? "BN128" : "  ", a.grid_gn, WDM_ABL, B, H, Cin, Cout, pro, grid, C::LDS_BYTES, ms / it * 1e3, fl / (ms / it) / 1e9);
+    printf("%s gn=%d ABL=%d B=%d H=%d %d->%d pro=%d grid=%d lds=%d : %.1f us  %.1f TFLOP/s\n", nthr == 512 ? "BN128" : "  ", a.grid_gn, WDM_ABL, B, H, Cin, Cout, pro, grid, C::LDS_BYTES, ms / it * 1e3, fl / (ms / it) / 1e9);
 #if (WDM_ABL & 16)
     {   // one instrumented launch; temb pointer is abused as the timestamp buffer (temb is added in the epilogue only when
         // non-null, so run with a copy of the args whose epilogue ignores it: y_mode stays, temb_ld = 0 rows of zeros)
