@@ -429,3 +429,47 @@ def synthetic_raindrop_dir(root, seed=303, sizes=((1000, 640), (300, 500), (720,
         Image.fromarray(rain).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
         Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
     return [list(s) for s in sizes]
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY.md §8(f)-3  training step   (reference: models/ddm_wavelet.py:108-124 loss, :200-272 step, :34-60 EMA,
+# utils/optimize.py:5-8 Adam(lr, betas=(0.9,0.999), eps, weight_decay, amsgrad=False))
+# ------------------------------------------------------------------------------------------------
+def noise_estimation_loss(sd, config, x0, t, e, betas):
+    """ddm_wavelet.py:108-124 for the raindrop_wavelet.yml branch (use_other_channels, inp_channels = 48, pred_channels = 3).
+    x0: (B, 96, R, R) = [x_cond 48 | gt LL 3 | other 45]; t: (B,) long; e: (B,3,R,R).  -> (simple_loss, output, x0_pred, mse_loss)"""
+    m = config.model
+    inp, pc = m.in_channels, m.pred_channels
+    a = (1 - betas).cumprod(dim=0).index_select(0, t).view(-1, 1, 1, 1)
+    x_inp, x_tar, x_other = x0[:, :inp], x0[:, inp:inp + pc], x0[:, inp + pc:]
+    xt = x_tar * a.sqrt() + e * (1.0 - a).sqrt()
+    output = unet_forward(sd, config, torch.cat([x_inp, xt, x_other], dim=1), t.float())
+    x0_pred = (xt - output * (1 - a).sqrt()) / a.sqrt()
+    simple_loss = (e - output).square().sum(dim=(1, 2, 3))
+    mse_loss = (x_tar - x0_pred).square().sum(dim=(1, 2, 3))
+    return simple_loss.mean(dim=0), output, x0_pred, mse_loss.mean(dim=0)
+
+
+def train_grads(sd, config, x0, t, e, betas):
+    """loss.backward() of the step above: -> (loss, {name: grad}) by torch autograd over the functional forward."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        loss, output, _, _ = noise_estimation_loss(leaf, config, x0, t, e, betas)
+        loss.backward()
+    return loss.detach(), output.detach(), {k: v.grad for k, v in leaf.items()}
+
+
+def adam_step(p, g, m, v, step, lr=4e-5, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam (amsgrad=False), one parameter tensor, `step` counted from 1.  Returns (p, m, v)."""
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = v.sqrt() / (bc2 ** 0.5) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+def ema_update(shadow, p, mu=0.9999):
+    """EMAHelper.update, ddm_wavelet.py:48-53 (the reference constructs EMAHelper() with its default mu = 0.9999)."""
+    return (1.0 - mu) * p + mu * shadow

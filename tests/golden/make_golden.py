@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--skip-full", action="store_true", help="skip the full-width (156 M) cases")
     ap.add_argument("--only-hfrm", action="store_true", help="regenerate hfrm.npz only")
     ap.add_argument("--only-io", action="store_true", help="regenerate io.npz only")
+    ap.add_argument("--only-train", action="store_true", help="regenerate train.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -165,6 +166,56 @@ def main():
         io["ds_sizes"] = np.array(sizes, dtype=np.int32)
         np.savez_compressed(out("io.npz"), **io)
 
+    # ------------------------------------------------------------------ training step
+    def golden_train():
+        print("[train]")
+        from models.ddm_wavelet import noise_estimation_loss, EMAHelper
+        torch.set_grad_enabled(True)
+        cfg_t = P.reduced_config()
+        sd_t = P.procedural_state_dict(cfg_t, seed=61)
+        net_t = RU.DiffusionUNet(cfg_t).train()
+        net_t.load_state_dict(sd_t, strict=True)
+        betas_t = torch.from_numpy(get_beta_schedule(beta_schedule="linear", beta_start=0.0001, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+        x0 = seeded((4, 96, 16, 16), 401)
+        e = seeded((4, 3, 16, 16), 402)
+        t = torch.tensor([990, 9, 500, 499])
+        ema = EMAHelper()
+        ema.register(net_t)
+        opt = torch.optim.Adam(net_t.parameters(), lr=0.00004, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=False, eps=0.00000001)
+        loss, output, x0_pred, mse = noise_estimation_loss(net_t, x0, t, e, betas_t, inp_channels=48, pred_channels=3, use_other_channels=True)
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net_t.named_parameters()}
+        o_loss, o_out, o_g = O.train_grads(sd_t, cfg_t, x0, t, e, betas_t)
+        check("train loss", o_loss.reshape(1), loss.detach().reshape(1))
+        check("train output", o_out, output.detach())
+        worst = max(rel_err(o_g[k], grads[k]) for k in grads)
+        print(f"  oracle vs reference  all {len(grads)} gradients: worst rel_linf = {worst:.3e}")
+        assert worst <= 1e-4
+        opt.step()
+        ema.update(net_t)
+        tr = {"loss": np.array(float(loss)), "mse": np.array(float(mse)), "output": output.detach().numpy(), "x0_pred": sub(x0_pred, 3),
+              "grad_names": np.array(list(grads.keys())),
+              "grad_absmax": np.array([float(g.abs().max()) for g in grads.values()]),
+              "grad_sum": np.array([float(g.double().sum()) for g in grads.values()])}
+        keep = ["conv_in.weight", "conv_out.bias", "temb.dense.0.weight", "down.0.block.0.conv1.weight", "down.0.block.0.norm1.weight",
+                "down.1.block.0.nin_shortcut.weight", "down.1.attn.0.q.weight", "down.1.attn.0.proj_out.bias", "mid.block_1.temb_proj.weight",
+                "mid.attn_1.k.bias", "up.0.block.2.conv2.weight", "up.1.block.0.norm2.bias", "up.1.upsample.conv.weight", "down.0.downsample.conv.weight"]
+        newp = dict(net_t.named_parameters())
+        for k in keep:
+            st = 1 if grads[k].numel() <= 4096 else 13            # fixed subsampling rule (the tests apply the same)
+            tr["g:" + k] = sub(grads[k], st)
+            tr["p1:" + k] = sub(newp[k], st)
+            tr["ema1:" + k] = sub(ema.shadow[k], st)
+            pn, _, _ = O.adam_step(sd_t[k], grads[k], torch.zeros_like(sd_t[k]), torch.zeros_like(sd_t[k]), 1)
+            assert rel_err(pn, newp[k].detach()) <= 1e-6, k
+            assert rel_err(O.ema_update(sd_t[k], pn), ema.shadow[k]) <= 1e-6, k
+        np.savez_compressed(out("train.npz"), **tr)
+        torch.set_grad_enabled(False)
+
+    if args.only_train:
+        golden_train()
+        return
     if args.only_hfrm:
         golden_hfrm()
         return
@@ -173,6 +224,7 @@ def main():
         return
     golden_hfrm()
     golden_io()
+    golden_train()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")

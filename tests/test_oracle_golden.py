@@ -153,3 +153,32 @@ def test_metrics_match_reference_golden(golden):
         assert abs(O.psnr_torch(g1, o1) - g["psnr"][k, 0]) < 1e-4
         assert abs(O.psnr_y(g1, o1) - g["psnr"][k, 1]) < 1e-4
         assert abs(O.psnr_y(g1, o1.clamp(0, 1)) - g["psnr"][k, 2]) < 1e-3     # numpy path: float32 Y on 0..255 data
+
+
+def _sub(t):
+    t = t.detach().flatten()
+    return t[:: (1 if t.numel() <= 4096 else 13)]
+
+
+def test_training_step_matches_reference_golden(golden):
+    """loss, every gradient, one Adam step and one EMA update of the oracle == the reference's own
+    noise_estimation_loss / autograd / torch.optim.Adam / EMAHelper on the reduced model."""
+    g = golden("train.npz")
+    cfg = P.reduced_config()
+    sd = P.procedural_state_dict(cfg, seed=61)
+    betas = O.beta_schedule(cfg)
+    x0, e, t = seeded((4, 96, 16, 16), 401), seeded((4, 3, 16, 16), 402), torch.tensor([990, 9, 500, 499])
+    loss, out, grads = O.train_grads(sd, cfg, x0, t, e, betas)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert rel_linf(out, torch.from_numpy(g["output"])) <= 1e-5
+    names = [str(n) for n in g["grad_names"]]
+    assert names == list(grads.keys())
+    for k, amax, gsum in zip(names, g["grad_absmax"], g["grad_sum"]):
+        assert abs(float(grads[k].abs().max()) - amax) <= 1e-4 * amax + 1e-12, k
+    for key in g.files:
+        if key.startswith("g:"):
+            k = key[2:]
+            assert rel_linf(_sub(grads[k]), torch.from_numpy(g[key])) <= 1e-5, k
+            p1, m1, v1 = O.adam_step(sd[k], grads[k], torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1)
+            assert rel_linf(_sub(p1), torch.from_numpy(g["p1:" + k])) <= 1e-6, k
+            assert rel_linf(_sub(O.ema_update(sd[k], p1)), torch.from_numpy(g["ema1:" + k])) <= 1e-6, k
