@@ -208,6 +208,13 @@ int wdm_hfrm_forward(wdm_hfrm* m, const float* x, int B, int H, int W, float* y,
 int wdm_image_sqdiff(wdm_handle* h, const float* a, const float* b, int B, int H, int W, double* sums, void* stream);
 int wdm_to_u8_hwc(wdm_handle* h, const float* x, int B, int C, int H, int W, uint8_t* y, void* stream);
 
+/* ---- training step: backward primitives, test entry points --------------------------
+ * wdm_conv_backward: autograd of one convolution of models/unet.py (mode as wdm_conv_forward: 0 conv3x3 s1 p1, 1 Downsample,
+ * 2 Upsample, 3 conv1x1).  x (B,cin,H,W), dy (B,cout,Ho,Wo), w OIHW f32 -> dx (B,cin,H,W) (optional), dw OIHW f32, db (cout) (optional). */
+int wdm_conv_backward(wdm_handle* h, const float* w, int cin, int cout, int mode, const float* x, const float* dy, int B,
+                      int H, int W, float* dx, float* dw, float* db, int dtype, void* scratch, size_t scratch_bytes,
+                      void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
  * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).

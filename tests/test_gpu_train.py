@@ -1,0 +1,50 @@
+"""GPU parity of the training-step primitives through the C ABI against torch autograd over the oracle's ops."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import rel_linf
+from gpu_util import DT, dev, scratch, seeded, _p
+from oracle import wavedm_oracle as O
+from wavedm_amd import _lib
+
+pytestmark = pytest.mark.gpu
+BTOL = {"f32": 1e-3, "bf16": 4e-2}
+
+
+def conv_backward(w, mode, x, dy, dtype, want_dx=True):
+    L, h = _lib.lib(), _lib.handle(0)
+    wd, xd, dyd = w.to(dev()).contiguous(), x.to(dev()).contiguous(), dy.to(dev()).contiguous()
+    B, cin, H, W = xd.shape
+    cout = wd.shape[0]
+    dx = torch.empty_like(xd) if want_dx else None
+    dw = torch.empty_like(wd)
+    db = torch.empty(cout, device=dev())
+    sc = scratch(1 << 30)
+    _lib.check(L.wdm_conv_backward(h, _p(wd), cin, cout, mode, _p(xd), _p(dyd), B, H, W, _p(dx), _p(dw), _p(db), DT[dtype], _p(sc), sc.numel(),
+                                   _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return (dx.cpu() if want_dx else None), dw.cpu(), db.cpu()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("mode,cin,cout,B,H", [
+    (0, 64, 128, 2, 16), (0, 128, 64, 3, 8), (0, 128, 3, 2, 16), (0, 96, 128, 1, 32),
+    (1, 64, 64, 2, 16), (2, 64, 64, 2, 8), (3, 64, 128, 2, 16), (3, 384, 128, 1, 16), (3, 160, 64, 3, 8),
+])
+def test_conv_backward(dtype, mode, cin, cout, B, H):
+    k = 1 if mode == 3 else 3
+    w = seeded((cout, cin, k, k), 500 + mode) / (cin * k * k) ** 0.5
+    b = seeded((cout,), 510 + mode) * 0.1
+    x = seeded((B, cin, H, H), 520 + mode + H).requires_grad_(True)
+    wl, bl = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    sd = {"c.conv.weight": wl, "c.conv.bias": bl, "c.weight": wl, "c.bias": bl}
+    with torch.enable_grad():
+        y = [lambda: O.conv(sd, "c", x, padding=1), lambda: O.downsample(sd, "c", x), lambda: O.upsample(sd, "c", x), lambda: O.conv(sd, "c", x)][mode]()
+        dy = seeded(tuple(y.shape), 530 + mode)
+        y.backward(dy)
+    dx, dw, db = conv_backward(w, mode, x.detach(), dy, dtype)
+    assert rel_linf(dx, x.grad) <= BTOL[dtype], ("dx", mode, cin, cout)
+    assert rel_linf(dw, wl.grad) <= BTOL[dtype], ("dw", mode, cin, cout)
+    assert rel_linf(db, bl.grad) <= BTOL[dtype], ("db", mode, cin, cout)

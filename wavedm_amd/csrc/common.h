@@ -161,6 +161,11 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);
 int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);
 void free_tens(Ctx& c, Tens& t);
 
+// ---- training step: backward primitives (train.hip) ---------------------------------------------------------------
+int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate);
+int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate);
+int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate);
+
 }  // namespace wdm
 
 struct wdm_handle {
