@@ -215,6 +215,12 @@ int wdm_conv_backward(wdm_handle* h, const float* w, int cin, int cout, int mode
                       int H, int W, float* dx, float* dw, float* db, int dtype, void* scratch, size_t scratch_bytes,
                       void* stream);
 
+/* wdm_gn_act_backward: autograd of GroupNorm(32, 1e-6)(+SiLU) (unet.py:31-37) over a channel concat [C0 | C - C0] of x (B,C,H,W);
+ * dy (B,C,H,W) -> dx (B,C,H,W), dgamma (C), dbeta (C). */
+int wdm_gn_act_backward(wdm_handle* h, const float* x, int C0, int C, const float* gamma, const float* beta, const float* dy,
+                        int silu, int B, int H, int W, float* dx, float* dgamma, float* dbeta, int dtype, void* scratch,
+                        size_t scratch_bytes, void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
  * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).

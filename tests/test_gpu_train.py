@@ -48,3 +48,38 @@ def test_conv_backward(dtype, mode, cin, cout, B, H):
     assert rel_linf(dx, x.grad) <= BTOL[dtype], ("dx", mode, cin, cout)
     assert rel_linf(dw, wl.grad) <= BTOL[dtype], ("dw", mode, cin, cout)
     assert rel_linf(db, bl.grad) <= BTOL[dtype], ("db", mode, cin, cout)
+
+
+def gn_act_backward(x, C0, gamma, beta, dy, silu, dtype):
+    L, h = _lib.lib(), _lib.handle(0)
+    xd, dyd, gd, bd = x.to(dev()).contiguous(), dy.to(dev()).contiguous(), gamma.to(dev()).contiguous(), beta.to(dev()).contiguous()
+    B, Cc, H, W = xd.shape
+    dx, dg, db = torch.empty_like(xd), torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    sc = scratch(1 << 28)
+    _lib.check(L.wdm_gn_act_backward(h, _p(xd), C0, Cc, _p(gd), _p(bd), _p(dyd), silu, B, H, W, _p(dx), _p(dg), _p(db), DT[dtype], _p(sc), sc.numel(),
+                                     _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return dx.cpu(), dg.cpu(), db.cpu()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("C,C0,B,H,silu", [(64, 64, 2, 16, 1), (128, 128, 3, 8, 0), (384, 256, 2, 16, 1), (1280, 768, 1, 8, 1), (32, 32, 2, 16, 1)])
+def test_gn_act_backward(dtype, C, C0, B, H, silu):
+    x = (seeded((B, C, H, H), 600 + C) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1.0 + 0.1 * seeded((C,), 601)).requires_grad_(True)
+    beta = (0.1 * seeded((C,), 602)).requires_grad_(True)
+    if dtype == "bf16":            # the device sees bf16 activations: give autograd the same rounded inputs
+        x = x.detach().bfloat16().float().requires_grad_(True)
+    with torch.enable_grad():
+        y = torch.nn.functional.group_norm(x, 32, gamma, beta, eps=1e-6)
+        if silu:
+            y = y * torch.sigmoid(y)
+        dy = seeded(tuple(y.shape), 603)
+        if dtype == "bf16":
+            dy = dy.bfloat16().float()
+        y.backward(dy)
+    dx, dg, db = gn_act_backward(x.detach(), C0, gamma.detach(), beta.detach(), dy, silu, dtype)
+    tol = 1e-3 if dtype == "f32" else 2e-2
+    assert rel_linf(dx, x.grad) <= tol
+    assert rel_linf(dg, gamma.grad) <= tol
+    assert rel_linf(db, beta.grad) <= tol

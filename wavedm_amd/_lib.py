@@ -95,6 +95,7 @@ def lib():
         "wdm_image_sqdiff": (i, [vp, vp, vp, i, i, i, vp, vp]),
         "wdm_to_u8_hwc": (i, [vp, vp, i, i, i, i, vp, vp]),
         "wdm_conv_backward": (i, [vp, vp, i, i, i, vp, vp, i, i, i, vp, vp, vp, i, vp, sz, vp]),
+        "wdm_gn_act_backward": (i, [vp, vp, i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp, sz, vp]),
         "wdm_prof_enable": (i, [i]),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
@@ -114,7 +115,7 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
-            "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_prof_enable", "wdm_prof_report"]
 
 
 def prof_enable(on: bool):

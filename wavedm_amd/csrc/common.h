@@ -123,7 +123,7 @@ int gn_default_nslab(int HW);
 size_t gn_stats_bytes(int B, int nslab, int C);
 int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s);
 int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw,
-                  float eps, int for_silu_conv, float* scale, float* shift, hipStream_t s);
+                  float eps, int for_silu_conv, float* scale, float* shift, hipStream_t s, float* mean_rstd = nullptr);   // mean_rstd: [B][32][2], optional
 // y[b][p][y_choff + c] = act(x*scale + shift); scale/shift rows are sc_ld long (channel concat: pass scale + C0), silu != 0 applies SiLU
 int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int sc_ld, void* y, int y_stride, int y_choff, int silu, int dtype,
                hipStream_t s);
@@ -165,6 +165,8 @@ void free_tens(Ctx& c, Tens& t);
 int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate);
 int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate);
 int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate);
+int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
+                    bool acc1, float* dgamma, float* dbeta, bool acc_param);
 
 }  // namespace wdm
 

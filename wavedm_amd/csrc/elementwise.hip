@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1,
                                                          int C, int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                         float premul, float* __restrict__ scale, float* __restrict__ shift) {
+                                                         float premul, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int gw = C / 32, C1 = C - C0;
     const int lane = threadIdx.x;
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     if (var < 0.0) var = 0.0;
     const float mean = (float)(kg + m);
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd != nullptr && lane == 0) { mean_rstd[((long long)b * 32 + g) * 2] = mean; mean_rstd[((long long)b * 32 + g) * 2 + 1] = rstd; }
     for (int ci = lane; ci < gw; ci += 64) {
         const int c = cg0 + ci;
         const float sc = rstd * gamma[c];
@@ -371,13 +372,13 @@ int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipSt
 }
 
 int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw, float eps, int for_silu_conv,
-                  float* scale, float* shift, hipStream_t s) {
+                  float* scale, float* shift, hipStream_t s, float* mean_rstd) {
     const int C = C0 + C1;
     if (C != nw.c || C % 32) WDM_FAIL(WDM_EINVAL, "groupnorm: %d channels vs %d weights (must be a multiple of 32)", C, nw.c);
     // for_silu_conv: the consumer is a conv with the fused GN+SiLU prologue, which wants scale/shift pre-multiplied by -log2(e)
     const float premul = for_silu_conv ? -1.4426950408889634f : 1.0f;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW,
-                       nw.g, nw.b, eps, premul, scale, shift);
+                       nw.g, nw.b, eps, premul, scale, shift, mean_rstd);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }

@@ -122,6 +122,69 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__
     }
 }
 
+// ---- GroupNorm (+ SiLU) backward (unet.py:31-37 under autograd).  One workgroup per (group, image).
+//   xh = (x - mean) rstd,  pre = xh g + b,  y = silu(pre) (or pre);   dv = dy * silu'(pre)
+//   dgamma_c = sum dv xh,  dbeta_c = sum dv   (per image here; summed over the batch by colsum afterwards)
+//   dx = rstd (dv g - mean_G(dv g) - xh mean_G(dv g xh)),   the group means being sum_c g_c dbeta_c / N and sum_c g_c dgamma_c / N
+// x = [x0 | x1] (channel concat), dy dense [B][HW][C]; dx0 / dx1 dense per source, optionally accumulated into.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
+                                                         const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean_rstd, int silu, T* __restrict__ dx0, int acc0, T* __restrict__ dx1, int acc1,
+                                                         float* __restrict__ dgam_part, float* __restrict__ dbet_part) {
+    __shared__ float red[2][4];
+    __shared__ float msum[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int gw = C / 32, cg0 = g * gw, C1 = C - C0;
+    const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
+    float Sa = 0.f, Sb = 0.f;                       // thread 0 only
+    for (int ci = 0; ci < gw; ++ci) {
+        const int c = cg0 + ci;
+        const float gm = gamma[c], bt = beta[c];
+        float sg = 0.f, sb = 0.f;
+        for (int p = tid; p < HW; p += 256) {
+            const long long bp = (long long)b * HW + p;
+            const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
+            const float xh = (xv - mean) * rstd;
+            float dv = TI<T>::ld(dy, bp * C + c);
+            if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
+            sg += dv * xh; sb += dv;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
+        if (lane == 0) { red[0][wv] = sg; red[1][wv] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            const float tg = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), tb = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+            dgam_part[(long long)b * C + c] = tg; dbet_part[(long long)b * C + c] = tb;
+            Sa += gm * tb; Sb += gm * tg;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { const float N = (float)gw * (float)HW; msum[0] = Sa / N; msum[1] = Sb / N; }
+    __syncthreads();
+    const float ma = msum[0], mb = msum[1];
+    const int total = HW * gw;
+    for (int id = tid; id < total; id += 256) {
+        const int p = id / gw, c = cg0 + (id - p * gw);
+        const long long bp = (long long)b * HW + p;
+        const float gm = gamma[c], bt = beta[c];
+        const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
+        const float xh = (xv - mean) * rstd;
+        float dv = TI<T>::ld(dy, bp * C + c);
+        if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
+        float d = rstd * (dv * gm - ma - xh * mb);
+        if (c < C0) { const long long o = bp * C0 + c; if (acc0) d += TI<T>::ld(dx0, o); TI<T>::st(dx0, o, d); }
+        else { const long long o = bp * C1 + (c - C0); if (acc1) d += TI<T>::ld(dx1, o); TI<T>::st(dx1, o, d); }
+    }
+}
+template <typename T>
+static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, const void* x1, int xs1, int C, int HW, const void* dy, const float* g, const float* bta,
+                         const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp) {
+    hipLaunchKernelGGL(gn_act_bwd_kernel<T>, dim3(32, B), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, (const T*)dy, g, bta, mr, silu, (T*)dx0, acc0,
+                       (T*)dx1, acc1, dgp, dbp);
+}
+
 static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
 
 // typed launch helpers ------------------------------------------------------------------------------------------------
@@ -287,6 +350,24 @@ int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate) 
     return WDM_OK;
 }
 
+
+// GroupNorm (+SiLU) backward over [x0 | x1]; mean_rstd from the forward's finalize.  dgamma / dbeta (+)= batch sums.
+int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
+                    bool acc1, float* dgamma, float* dbeta, bool acc_param) {
+    const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
+    float* part = (float*)c.ar->alloc((size_t)2 * c.B * C * sizeof(float));
+    if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm backward)");
+    if (!c.dry) {
+        BY_DTYPE(c.dtype, l_gn_act_bwd, c.s, c.B, x0.p, x0.xs, x0.C, x1 ? x1->p : x0.p, x1 ? x1->xs : 0, C, HW, dy.p, nw.g, nw.b, mean_rstd, silu, dx0, acc0 ? 1 : 0,
+                 x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C);
+        l_colsum<float>(c.s, part, C, C, c.B, 1, dgamma, acc_param ? 1 : 0);
+        l_colsum<float>(c.s, part + (size_t)c.B * C, C, C, c.B, 1, dbeta, acc_param ? 1 : 0);
+        WDM_HIP(hipGetLastError());
+    }
+    c.ar->free(part);
+    return WDM_OK;
+}
+
 }  // namespace wdm
 
 // =================================================================================================
@@ -316,4 +397,49 @@ extern "C" int wdm_conv_backward(wdm_handle* h, const float* w, int cin, int cou
     WDM_TRY(conv_wgrad(c, mode, tx, nullptr, tdy, cout, dw, false));
     if (db) WDM_TRY(colsum(c, tdy, db, false, false));
     return WDM_OK;
+}
+
+extern "C" int wdm_gn_act_backward(wdm_handle* h, const float* x, int C0, int C, const float* gamma, const float* beta, const float* dy, int silu, int B, int H, int W,
+                                   float* dx, float* dgamma, float* dbeta, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!h || !x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !scratch) WDM_FAIL(WDM_EINVAL, "wdm_gn_act_backward: null argument");
+    if (C % 32 || C0 <= 0 || C0 > C) WDM_FAIL(WDM_EINVAL, "wdm_gn_act_backward: bad channel split");
+    Arena ar(scratch, scratch_bytes);
+    Ctx c{(hipStream_t)stream, dtype, B, &ar, false};
+    const size_t es = dsize(dtype);
+    const int HW = H * W, C1 = C - C0;
+    // the block input arrives as ONE NCHW tensor; split it into the two NHWC sources the executor would hold
+    void* full = ar.alloc((size_t)B * HW * C * es);
+    Tens tdy; tdy.p = ar.alloc((size_t)B * HW * C * es); tdy.C = C; tdy.H = H; tdy.W = W; tdy.xs = C;
+    void* d0 = ar.alloc((size_t)B * HW * C0 * es);
+    void* d1 = C1 ? ar.alloc((size_t)B * HW * C1 * es) : nullptr;
+    void* dfull = ar.alloc((size_t)B * HW * C * es);
+    float* mr = (float*)ar.alloc((size_t)B * 64 * sizeof(float));
+    float *sc = (float*)ar.alloc((size_t)B * C * 4), *sh = (float*)ar.alloc((size_t)B * C * 4);
+    if (!full || !tdy.p || !d0 || (C1 && !d1) || !dfull || !mr || !sc || !sh) WDM_FAIL(WDM_ENOMEM, "wdm_gn_act_backward: scratch too small");
+    WDM_TRY(k_nchw_to_nhwc(x, full, B, C, H, W, dtype, c.s));
+    WDM_TRY(k_nchw_to_nhwc(dy, tdy.p, B, C, H, W, dtype, c.s));
+    Tens t0, t1;
+    t0.p = full; t0.C = C0; t0.H = H; t0.W = W; t0.xs = C;
+    t1.p = (char*)full + (size_t)C0 * es; t1.C = C1; t1.H = H; t1.W = W; t1.xs = C;
+    NormW nw; nw.g = gamma; nw.b = beta; nw.c = C;
+    const int ns = gn_default_nslab(HW);
+    float* st0 = (float*)ar.alloc(gn_stats_bytes(B, ns, C0));
+    float* st1 = C1 ? (float*)ar.alloc(gn_stats_bytes(B, ns, C1)) : nullptr;
+    if (!st0 || (C1 && !st1)) WDM_FAIL(WDM_ENOMEM, "wdm_gn_act_backward: scratch too small");
+    WDM_TRY(k_gn_partial(t0, B, st0, ns, dtype, c.s));
+    if (C1) WDM_TRY(k_gn_partial(t1, B, st1, ns, dtype, c.s));
+    WDM_TRY(k_gn_finalize(B, HW, st0, ns, C0, st1, ns, C1, nw, 1e-6f, 0, sc, sh, c.s, mr));
+    WDM_TRY(gn_act_backward(c, nw, t0, C1 ? &t1 : nullptr, mr, tdy, silu, d0, false, d1, false, dgamma, dbeta, false));
+    // reassemble (B, C, H, W): dx = [d0 | d1]
+    {
+        Tens o0; o0.p = d0; o0.C = C0; o0.H = H; o0.W = W; o0.xs = C0;
+        // identity "apply" = copy into the concat layout: scale 1, shift 0 rows
+        WDM_HIP(hipMemsetAsync(sh, 0, (size_t)B * C * 4, c.s));
+        std::vector<float> ones((size_t)B * C, 1.0f);
+        WDM_HIP(hipMemcpyAsync(sc, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, c.s));
+        WDM_HIP(hipStreamSynchronize(c.s));
+        WDM_TRY(k_gn_apply(o0, B, sc, sh, C, dfull, C, 0, 0, dtype, c.s));
+        if (C1) { Tens o1; o1.p = d1; o1.C = C1; o1.H = H; o1.W = W; o1.xs = C1; WDM_TRY(k_gn_apply(o1, B, sc, sh, C, dfull, C, C0, 0, dtype, c.s)); }
+    }
+    return k_nhwc_to_nchw(dfull, dx, B, C, H, W, dtype, c.s);
 }
