@@ -221,6 +221,27 @@ int wdm_gn_act_backward(wdm_handle* h, const float* x, int C0, int C, const floa
                         int silu, int B, int H, int W, float* dx, float* dgamma, float* dbeta, int dtype, void* scratch,
                         size_t scratch_bytes, void* stream);
 
+/* ---- training step object -----------------------------------------------------------
+ * Replaces the body of DenoisingDiffusion_Wavelet.train's inner loop (models/ddm_wavelet.py:259-272) for the raindrop_wavelet.yml
+ * branch: noise_estimation_loss (:108-124) forward + backward, torch.optim.Adam step (utils/optimize.py:5-8) and EMAHelper.update
+ * (:48-53).  Parameters, gradients, Adam moments and the EMA shadow are five caller-allocated flat fp32 DEVICE buffers sharing one
+ * layout (wdm_trainer_param_info gives name, shape and float offset of every state_dict entry; the temb_proj layers sit at the end as
+ * one [rows][4ch] matrix).  A data-parallel job all-reduces the gradient buffer between _step and _adam_ema.
+ *   x0 (B, in_channels, R, R) f32: [x_cond | x_tar | x_other] in the wavelet domain; e (B, out_ch, R, R) noise; t (B) timesteps as
+ *   float; sqrt_a / sqrt_1ma (B): sqrt(abar_t), sqrt(1 - abar_t) (device); c_t0: first channel of x_tar.
+ *   loss (device float) = mean_b sum (e - out)^2; out_nchw (optional): the network output. */
+typedef struct wdm_trainer wdm_trainer;
+int wdm_trainer_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_trainer** out);
+int wdm_trainer_destroy(wdm_trainer* t);
+int wdm_trainer_num_params(const wdm_trainer* t);
+int64_t wdm_trainer_num_floats(const wdm_trainer* t);
+int wdm_trainer_param_info(const wdm_trainer* t, int i, const char** name, int* ndim, int64_t shape[4], int64_t* offset);
+int wdm_trainer_set_buffers(wdm_trainer* t, float* params, float* grads, float* m, float* v, float* ema);
+int wdm_trainer_step(wdm_trainer* t, const float* x0, const float* tt, const float* sqrt_a, const float* sqrt_1ma, const float* e,
+                     int B, int c_t0, float* loss, float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
+int wdm_trainer_adam_ema(wdm_trainer* t, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float ema_mu, void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and
  * tagged with its algorithmic flops (2*M*N*K) and bytes (input + weights + output once).

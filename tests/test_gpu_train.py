@@ -83,3 +83,77 @@ def test_gn_act_backward(dtype, C, C0, B, H, silu):
     assert rel_linf(dx, x.grad) <= tol
     assert rel_linf(dg, gamma.grad) <= tol
     assert rel_linf(db, beta.grad) <= tol
+
+
+def _sub(t):
+    t = t.detach().flatten()
+    return t[:: (1 if t.numel() <= 4096 else 13)]
+
+
+def _trainer(dtype):
+    from wavedm_amd import procedural as P
+    from wavedm_amd.training import Trainer
+    cfg = P.reduced_config()
+    cfg.device = dev()
+    tr = Trainer(cfg, dtype=dtype, lr=4e-5, eps=1e-8)
+    tr.load_state_dict(P.procedural_state_dict(cfg, seed=61))
+    return tr, cfg
+
+
+def test_trainer_layout_matches_reference_state_dict():
+    from wavedm_amd import procedural as P
+    tr, cfg = _trainer("f32")
+    want = P.unet_param_shapes(cfg)
+    assert set(tr.layout) == set(want)
+    assert all(tuple(tr.layout[k][1]) == tuple(want[k]) for k in want)
+    sd = tr.state_dict()
+    ref = P.procedural_state_dict(cfg, seed=61)
+    assert all(torch.equal(sd[k].cpu(), ref[k]) for k in ref)
+
+
+def test_training_step_matches_reference_golden(golden):
+    """loss, network output, every gradient, one Adam step and one EMA update == the reference's own training step (f32 mode)."""
+    g = golden("train.npz")
+    tr, cfg = _trainer("f32")
+    x0, e, t = seeded((4, 96, 16, 16), 401).to(dev()), seeded((4, 3, 16, 16), 402).to(dev()), torch.tensor([990, 9, 500, 499])
+    loss, out = tr.loss_and_grads(x0, t, e, return_output=True)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    assert rel_linf(out.cpu(), torch.from_numpy(g["output"])) <= 1e-3
+    grads = tr.grad_dict()
+    names = [str(n) for n in g["grad_names"]]
+    # some gradients are mathematically zero (a bias in front of a one-channel-per-group GroupNorm, the k bias of the attention):
+    # both sides hold rounding noise there, so errors are measured against the largest gradient of the model as a floor
+    floor = 1e-4 * float(g["grad_absmax"].max())
+    worst = 0.0
+    for k, amax in zip(names, g["grad_absmax"]):
+        got = float(grads[k].abs().max())
+        worst = max(worst, abs(got - amax) / max(amax, floor))
+    assert worst <= 5e-3, worst
+    for key in g.files:
+        if key.startswith("g:"):
+            k = key[2:]
+            want = torch.from_numpy(g[key])
+            err = float((_sub(grads[k]).cpu() - want).abs().max()) / max(float(want.abs().max()), floor)
+            assert err <= 2e-3, (k, err)
+    tr.optimizer_step()
+    sd, ema = tr.state_dict(), tr.ema_state_dict()
+    for key in g.files:
+        if key.startswith("p1:"):
+            k = key[3:]
+            if float(torch.from_numpy(g["g:" + k]).abs().max()) < floor:
+                # a mathematically zero gradient: Adam's first step is lr * sign(rounding noise) on both sides
+                assert float((_sub(sd[k]).cpu() - torch.from_numpy(g[key])).abs().max()) <= 2.1 * tr.lr, k
+                continue
+            assert rel_linf(_sub(sd[k]).cpu(), torch.from_numpy(g[key])) <= 1e-5, k
+            assert rel_linf(_sub(ema[k]).cpu(), torch.from_numpy(g["ema1:" + k])) <= 1e-5, k
+
+
+def test_training_step_bf16_tracks_f32():
+    trf, _ = _trainer("f32")
+    trb, _ = _trainer("bf16")
+    x0, e, t = seeded((4, 96, 16, 16), 401).to(dev()), seeded((4, 3, 16, 16), 402).to(dev()), torch.tensor([990, 9, 500, 499])
+    lf, lb = float(trf.loss_and_grads(x0, t, e)), float(trb.loss_and_grads(x0, t, e))
+    assert abs(lf - lb) <= 2e-2 * abs(lf)
+    gf, gb = trf.grads, trb.grads
+    cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
+    assert cos >= 0.98, cos

@@ -96,6 +96,14 @@ def lib():
         "wdm_to_u8_hwc": (i, [vp, vp, i, i, i, i, vp, vp]),
         "wdm_conv_backward": (i, [vp, vp, i, i, i, vp, vp, i, i, i, vp, vp, vp, i, vp, sz, vp]),
         "wdm_gn_act_backward": (i, [vp, vp, i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp, sz, vp]),
+        "wdm_trainer_create": (i, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),
+        "wdm_trainer_destroy": (i, [vp]),
+        "wdm_trainer_num_params": (i, [vp]),
+        "wdm_trainer_num_floats": (i64, [vp]),
+        "wdm_trainer_param_info": (i, [vp, i, C.POINTER(C.c_char_p), C.POINTER(i), C.POINTER(i64 * 4), C.POINTER(i64)]),
+        "wdm_trainer_set_buffers": (i, [vp, vp, vp, vp, vp, vp]),
+        "wdm_trainer_step": (i, [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]),
+        "wdm_trainer_adam_ema": (i, [vp, i64, f, f, f, f, f, f, vp]),
         "wdm_prof_enable": (i, [i]),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
@@ -115,7 +123,8 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
-            "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
+            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_prof_enable", "wdm_prof_report"]
 
 
 def prof_enable(on: bool):

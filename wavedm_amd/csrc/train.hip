@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restri
 }
 // out[g][c] (+)= sum over the rows of group g of x[row][c]; rows_per_group rows per group (bias grad: one group; temb grad: one per image)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int xs, int C, long long rows_per_group, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int xs, int C, long long rows_per_group, float* __restrict__ out, int out_ld, int accumulate) {
     __shared__ float red[256];
     const int g = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     __syncthreads();
     if (sl == 0 && c < C) {
         const float t = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        out[(long long)g * C + c] = accumulate ? out[(long long)g * C + c] + t : t;
+        out[(long long)g * out_ld + c] = accumulate ? out[(long long)g * out_ld + c] + t : t;
     }
 }
 // Downsample dgrad helper: z[b][2oy+1][2ox+1][c] = dy[b][oy][ox][c], zero elsewhere (z is H x W, dy is H/2 x W/2)
@@ -216,8 +216,8 @@ template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, in
 template <typename T> static void l_pad_channels(hipStream_t s, const void* x, int C, int Cp, void* y, long long total) {
     hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)x, C, Cp, (T*)y, total);
 }
-template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc) {
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 63) / 64, groups), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, out, acc);
+template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc, int out_ld = 0) {
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 63) / 64, groups), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, out, out_ld ? out_ld : C, acc);
 }
 
 // ---- dgrad: dx (+)= conv^T(dy).  (H, W) is the forward INPUT map; dy is dense NHWC [B][Ho][Wo][cout]; dx dense [B][H][W][cin].
@@ -342,10 +342,10 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
 }
 
 // db[c] (+)= sum over all rows of dy;  per_image: out[b][c] = sum over the image's rows (temb gradient)
-int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate) {
+int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, int out_ld) {
     if (c.dry) return WDM_OK;
     const long long rows = (long long)dy.H * dy.W * (per_image ? 1 : c.B);
-    BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, per_image ? c.B : 1, out, accumulate ? 1 : 0);
+    BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, per_image ? c.B : 1, out, accumulate ? 1 : 0, out_ld);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -367,6 +367,15 @@ int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, con
     c.ar->free(part);
     return WDM_OK;
 }
+
+// dst[b][c][n] = src[b][n][c]  (tokens n = 0..N-1, dense rows of C): the attention backward's operand transposes
+int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst) {
+    if (c.dry) return WDM_OK;
+    BY_DTYPE(c.dtype, gather_t, c.s, src, Cc, 0, Cc, c.B, 1, N, 1, N, 1, 0, 0, dst, Cc, N);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+void l_colsum_f32(hipStream_t s, const float* x, int C, int rows, float* out) { l_colsum<float>(s, x, C, C, rows, 1, out, 0); }
 
 }  // namespace wdm
 

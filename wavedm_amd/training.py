@@ -1,0 +1,149 @@
+"""Training step of the wavelet-domain UNet on the HIP library.
+
+`Trainer(config)` owns five flat fp32 device buffers -- parameters, gradients, Adam m / v, EMA shadow -- in the layout the library
+reports (`wdm_trainer_param_info`), and runs the body of the reference's training loop (`models/ddm_wavelet.py:259-272`):
+
+    loss = trainer.loss_and_grads(x0, t, e)     # noise_estimation_loss (:108-124) forward + backward
+    trainer.allreduce_grads()                   # what DistributedDataParallel does in the reference (:168), one RCCL all-reduce
+    trainer.optimizer_step()                    # torch.optim.Adam (utils/optimize.py:5-8) + EMAHelper.update (:48-53)
+
+`state_dict()` / `load_state_dict()` use the reference's keys and shapes, `ema_state_dict()` is `EMAHelper.state_dict()`; a checkpoint
+written by `save_checkpoint` has the reference's dict format (ddm_wavelet.py:282-292) and loads in `DenoisingDiffusion_Wavelet`."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib, sampling
+from .unet import _make_config, resolve_dtype
+
+
+class Trainer:
+    def __init__(self, config, device=None, dtype=None, lr=None, betas=(0.9, 0.999), eps=None, weight_decay=None, ema_mu=0.9999):
+        self.config = config
+        self.device = torch.device(device if device is not None else getattr(config, "device", "cuda:0"))
+        if self.device.type != "cuda":
+            raise RuntimeError("wavedm_amd.Trainer runs on MI355X only (no CPU path)")
+        self._dtype_code = resolve_dtype(config, dtype)
+        opt = getattr(config, "optim", None)
+        self.lr = float(lr if lr is not None else getattr(opt, "lr", 4e-5))
+        self.eps = float(eps if eps is not None else getattr(opt, "eps", 1e-8))
+        self.weight_decay = float(weight_decay if weight_decay is not None else getattr(opt, "weight_decay", 0.0))
+        self.betas, self.ema_mu = (float(betas[0]), float(betas[1])), float(ema_mu)
+        L = _lib.lib()
+        self._cfg = _make_config(config, self._dtype_code)
+        t = C.c_void_p()
+        _lib.check(L.wdm_trainer_create(None, C.byref(self._cfg), C.byref(t)))
+        self._t = t
+        self.layout = OrderedDict()                     # name -> (offset, shape)
+        name, ndim, shape, off = C.c_char_p(), C.c_int(), (C.c_int64 * 4)(), C.c_int64()
+        for i in range(L.wdm_trainer_num_params(t)):
+            _lib.check(L.wdm_trainer_param_info(t, i, C.byref(name), C.byref(ndim), C.byref(shape), C.byref(off)))
+            self.layout[name.value.decode()] = (int(off.value), tuple(int(shape[k]) for k in range(ndim.value)))
+        n = int(L.wdm_trainer_num_floats(t))
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(n, device=self.device)
+            self.grads = torch.zeros(n, device=self.device)
+            self.exp_avg = torch.zeros(n, device=self.device)
+            self.exp_avg_sq = torch.zeros(n, device=self.device)
+            self.ema = torch.zeros(n, device=self.device)
+        _lib.check(L.wdm_trainer_set_buffers(t, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.ema)))
+        betas_t = sampling.get_beta_schedule(beta_schedule=config.diffusion.beta_schedule, beta_start=config.diffusion.beta_start,
+                                             beta_end=config.diffusion.beta_end, num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
+        self.betas_t = torch.from_numpy(betas_t).float().to(self.device)
+        self.num_timesteps = int(self.betas_t.shape[0])
+        self.step = 0
+        self._ws = None
+        m = config.model
+        self._c_t0 = int(m.in_channels)                 # x0 = [x_cond (in_channels) | x_tar (pred_channels) | x_other]
+        self._loss = torch.zeros(1, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_t", None):
+                _lib.lib().wdm_trainer_destroy(self._t)
+                self._t = None
+        except Exception:
+            pass
+
+    # ---- parameters in the reference's naming ----------------------------------------------------------------------
+    def _view(self, flat, name):
+        off, shape = self.layout[name]
+        n = 1
+        for v in shape:
+            n *= v
+        return flat[off:off + n].view(shape)
+
+    def state_dict(self):
+        return OrderedDict((k, self._view(self.params, k).clone()) for k in self.layout)
+
+    def ema_state_dict(self):
+        return OrderedDict((k, self._view(self.ema, k).clone()) for k in self.layout)
+
+    def grad_dict(self):
+        return OrderedDict((k, self._view(self.grads, k).clone()) for k in self.layout)
+
+    def load_state_dict(self, sd, strict=True, init_ema=True):
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        missing = [k for k in self.layout if k not in sd]
+        extra = [k for k in sd if k not in self.layout]
+        if strict and (missing or extra):
+            raise RuntimeError(f"Trainer.load_state_dict: missing {missing[:4]}, unexpected {extra[:4]}")
+        for k in self.layout:
+            if k in sd:
+                self._view(self.params, k).copy_(sd[k].to(self.device, torch.float32))
+        if init_ema:
+            self.ema.copy_(self.params)                 # EMAHelper.register (ddm_wavelet.py:40-46)
+
+    # ---- one step ----------------------------------------------------------------------------------------------------
+    def loss_and_grads(self, x0, t, e, return_output=False):
+        """x0 (B, 96, R, R) wavelet-domain [x_cond | x_tar | x_other]; t (B,) long; e (B, 3, R, R).  Fills self.grads; returns the
+        loss as a 0-dim device tensor (and the network output when asked)."""
+        x0 = _lib.require_cuda_f32(x0, "x0")
+        e = _lib.require_cuda_f32(e, "e")
+        B, Cc, R, _ = x0.shape
+        t = t.to(self.device)
+        a = (1 - self.betas_t).cumprod(dim=0).index_select(0, t.long())          # ddm_wavelet.py:109
+        sa, s1m = a.sqrt().contiguous(), (1.0 - a).sqrt().contiguous()
+        tf = t.float().contiguous()
+        out = torch.empty(B, int(self.config.model.out_ch), R, R, device=self.device) if return_output else None
+        with torch.cuda.device(self.device):
+            if self._ws is None or self._ws[0] < B:
+                # saved activations + gradients + operand transposes: sized generously from the batch (288 GB of HBM)
+                per_img = 96 * R * R * 4 * 400
+                self._ws = (B, torch.empty(B * per_img + (1 << 28), dtype=torch.uint8, device=self.device))
+            ws = self._ws[1]
+            _lib.check(_lib.lib().wdm_trainer_step(self._t, _lib.ptr(x0), _lib.ptr(tf), _lib.ptr(sa), _lib.ptr(s1m), _lib.ptr(e), B, self._c_t0, _lib.ptr(self._loss),
+                                                   _lib.ptr(out) if out is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        return (self._loss[0], out) if return_output else self._loss[0]
+
+    def allreduce_grads(self, group=None):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+            self.grads.div_(dist.get_world_size(group))              # DDP averages
+
+    def optimizer_step(self):
+        self.step += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().wdm_trainer_adam_ema(self._t, self.step, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.ema_mu,
+                                                       _lib.stream_ptr()))
+
+    def train_step(self, x0, group=None, generator=None):
+        """The body of the reference's loop for one batch of wavelet-domain samples x0 (B,96,R,R): noise, antithetic timesteps
+        (ddm_wavelet.py:249-256), loss, backward, all-reduce, Adam, EMA.  Returns the loss (device tensor)."""
+        n = x0.shape[0]
+        e = torch.randn((n, int(self.config.model.out_ch)) + tuple(x0.shape[2:]), device=self.device, generator=generator)
+        t = torch.randint(low=0, high=self.num_timesteps, size=(n // 2 + 1,), device=self.device, generator=generator)
+        t = torch.cat([t, self.num_timesteps - t - 1], dim=0)[:n]
+        loss = self.loss_and_grads(x0, t, e)
+        self.allreduce_grads(group)
+        self.optimizer_step()
+        return loss
+
+    def save_checkpoint(self, path, epoch=0):
+        torch.save({"epoch": epoch, "step": self.step, "state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
+                    "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step, "lr": self.lr},
+                    "ema_helper": {k: v.cpu() for k, v in self.ema_state_dict().items()}, "params": None, "config": None}, path)
