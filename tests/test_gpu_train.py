@@ -157,3 +157,27 @@ def test_training_step_bf16_tracks_f32():
     gf, gb = trf.grads, trb.grads
     cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
     assert cos >= 0.98, cos
+
+
+def test_training_step_full_width_f32():
+    """Full raindrop_wavelet UNet (156 M parameters, attention at 16x16), 2 samples: loss and a spread of gradients vs torch autograd over
+    the oracle on the host."""
+    from wavedm_amd import procedural as P
+    from wavedm_amd.training import Trainer
+    cfg = P.raindrop_wavelet_config()
+    cfg.device = dev()
+    sd = P.procedural_state_dict(cfg, seed=61)
+    tr = Trainer(cfg, dtype="f32")
+    tr.load_state_dict(sd)
+    x0, e, t = seeded((2, 96, 64, 64), 411), seeded((2, 3, 64, 64), 412), torch.tensor([700, 120])
+    loss = float(tr.loss_and_grads(x0.to(dev()), t, e.to(dev())))
+    ol, _, og = O.train_grads(sd, cfg, x0, t, e, O.beta_schedule(cfg))
+    assert abs(loss - float(ol)) <= 1e-4 * abs(float(ol))
+    g = tr.grad_dict()
+    floor = 1e-4 * max(float(v.abs().max()) for v in og.values())
+    for k in ["conv_in.weight", "down.0.block.1.conv2.weight", "down.1.downsample.conv.weight", "down.2.attn.0.q.weight", "down.2.attn.1.v.bias",
+              "down.3.block.0.nin_shortcut.weight", "mid.attn_1.proj_out.weight", "mid.block_2.norm1.weight", "up.3.block.0.conv1.weight",
+              "up.2.block.2.nin_shortcut.weight", "up.2.attn.1.k.weight", "up.1.upsample.conv.weight", "up.0.block.2.temb_proj.weight",
+              "temb.dense.0.weight", "temb.dense.1.bias", "norm_out.bias", "conv_out.weight"]:
+        err = float((g[k].cpu() - og[k]).abs().max()) / max(float(og[k].abs().max()), floor)
+        assert err <= 2e-3, (k, err)

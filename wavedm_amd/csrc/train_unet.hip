@@ -18,7 +18,8 @@ using namespace wdm;
 
 namespace wdm {
 
-static inline int nb(long long n, int bs) { long long g = (n + bs - 1) / bs; return (int)(g > 16384 ? 16384 : g); }
+static inline int nb(long long n, int bs) { long long g = (n + bs - 1) / bs; return (int)(g > 16384 ? 16384 : g); }      // grid-stride kernels
+static inline int nbu(long long n, int bs) { return (int)((n + bs - 1) / bs); }                                            // one element per thread
 
 // ---- small kernels -------------------------------------------------------------------------------------------------
 // x96[b][p][c] (NHWC, model dtype): c in [c_t0, c_t0 + 3): x0*sa[b] + e*s1m[b]  (q-sample, ddm_wavelet.py:112), else x0
@@ -451,9 +452,9 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     if (!emb || !pre0 || !t0 || !t1 || !s1 || !temb_all || !d_temb_all) WDM_FAIL(WDM_ENOMEM, "training workspace too small (temb)");
     WDM_TRY(k_timestep_embedding(t, B, cfg.ch, emb, cc.s));
     WDM_TRY(k_linear(emb, B, cfg.ch, P + d0w, P + d0b, temb_ch, pre0, 0, cc.s));
-    hipLaunchKernelGGL(silu_f32_kernel, dim3(nb((long long)B * temb_ch, 256)), dim3(256), 0, cc.s, pre0, t0, (long long)B * temb_ch);
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(nbu((long long)B * temb_ch, 256)), dim3(256), 0, cc.s, pre0, t0, (long long)B * temb_ch);
     WDM_TRY(k_linear(t0, B, temb_ch, P + d1w, P + d1b, temb_ch, t1, 0, cc.s));
-    hipLaunchKernelGGL(silu_f32_kernel, dim3(nb((long long)B * temb_ch, 256)), dim3(256), 0, cc.s, t1, s1, (long long)B * temb_ch);
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(nbu((long long)B * temb_ch, 256)), dim3(256), 0, cc.s, t1, s1, (long long)B * temb_ch);
     WDM_TRY(k_linear(s1, B, temb_ch, P + tw, P + tb, temb_rows, temb_all, 0, cc.s));
     WDM_HIP(hipMemsetAsync(d_temb_all, 0, (size_t)B * temb_rows * 4, cc.s));
     // ---- network input: [x_cond | x_t | x_other] with x_t = sqrt(a) x_tar + sqrt(1-a) e
@@ -523,15 +524,15 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
         const long long n4 = (long long)B * temb_ch;
         float *d_s1 = af(n4), *d_t1 = af(n4), *d_t0 = af(n4), *d_pre0 = af(n4);
         if (!d_s1 || !d_t1 || !d_t0 || !d_pre0) WDM_FAIL(WDM_ENOMEM, "training workspace too small (temb backward)");
-        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nb((long long)temb_rows * temb_ch, 256)), dim3(256), 0, cc.s, d_temb_all, s1, B, temb_rows, temb_ch, G + tw);
+        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_rows * temb_ch, 256)), dim3(256), 0, cc.s, d_temb_all, s1, B, temb_rows, temb_ch, G + tw);
         l_colsum_f32(cc.s, d_temb_all, temb_rows, B, G + tb);
-        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nb(n4, 256)), dim3(256), 0, cc.s, d_temb_all, P + tw, B, temb_rows, temb_ch, d_s1);
-        hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nb(n4, 256)), dim3(256), 0, cc.s, t1, d_s1, d_t1, n4);
-        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nb((long long)temb_ch * temb_ch, 256)), dim3(256), 0, cc.s, d_t1, t0, B, temb_ch, temb_ch, G + d1w);
+        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, d_temb_all, P + tw, B, temb_rows, temb_ch, d_s1);
+        hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, t1, d_s1, d_t1, n4);
+        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_ch * temb_ch, 256)), dim3(256), 0, cc.s, d_t1, t0, B, temb_ch, temb_ch, G + d1w);
         l_colsum_f32(cc.s, d_t1, temb_ch, B, G + d1b);
-        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nb(n4, 256)), dim3(256), 0, cc.s, d_t1, P + d1w, B, temb_ch, temb_ch, d_t0);
-        hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nb(n4, 256)), dim3(256), 0, cc.s, pre0, d_t0, d_pre0, n4);
-        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nb((long long)temb_ch * cfg.ch, 256)), dim3(256), 0, cc.s, d_pre0, emb, B, temb_ch, cfg.ch, G + d0w);
+        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, d_t1, P + d1w, B, temb_ch, temb_ch, d_t0);
+        hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, pre0, d_t0, d_pre0, n4);
+        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_ch * cfg.ch, 256)), dim3(256), 0, cc.s, d_pre0, emb, B, temb_ch, cfg.ch, G + d0w);
         l_colsum_f32(cc.s, d_pre0, temb_ch, B, G + d0b);
         WDM_HIP(hipGetLastError());
     }
