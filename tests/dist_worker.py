@@ -43,8 +43,19 @@ def main(out_path):
     corners = [(i, j) for i in (0, 4, 8) for j in (0, 4, 8, 12)]
     xs, x0 = d.sample_image(x_cond, noise, x_other=x_cond[:, 3:].contiguous(), last=False, patch_locs=corners, patch_size=16, use_other=True)
     d.patch_group = None
+    # (3) data-parallel training step: each rank back-propagates its half of the batch, one all-reduce averages the gradients
+    from wavedm_amd.training import Trainer
+    from gpu_util import seeded
+    tr = Trainer(cfg, dtype="f32")
+    tr.load_state_dict(P.procedural_state_dict(cfg, seed=61))
+    bx, be, bt = seeded((4, 96, 16, 16), 401), seeded((4, 3, 16, 16), 402), torch.tensor([990, 9, 500, 499])
+    lo, hi = parallel.shard_range(4, rank, world)
+    tr.loss_and_grads(bx[lo:hi].to(dev), bt[lo:hi], be[lo:hi].to(dev))
+    tr.allreduce_grads()
+    tr.optimizer_step()
     if rank == 0:
-        torch.save({"out_img": out_img.cpu(), "xs_last": xs[-1].cpu(), "x0_m5": x0[-5].cpu(), "world": world}, out_path)
+        torch.save({"out_img": out_img.cpu(), "xs_last": xs[-1].cpu(), "x0_m5": x0[-5].cpu(), "world": world,
+                    "grads": tr.grads.cpu(), "params1": tr.params.cpu()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -45,3 +45,14 @@ def test_two_ranks_match_single_process(tmp_path):
     xs, x0 = d.sample_image(x_cond, noise, x_other=x_cond[:, 3:].contiguous(), last=False, patch_locs=corners, patch_size=16, use_other=True)
     assert rel_linf(got["xs_last"], xs[-1].cpu()) <= 1e-5         # only the association of the overlap sums differs
     assert rel_linf(got["x0_m5"], x0[-5].cpu()) <= 1e-5
+    # data-parallel training step == the single-process step on the whole batch
+    from gpu_util import seeded
+    from wavedm_amd.training import Trainer
+    tr = Trainer(cfg, dtype="f32")
+    tr.load_state_dict(P.procedural_state_dict(cfg, seed=61))
+    tr.loss_and_grads(seeded((4, 96, 16, 16), 401).to(dev), torch.tensor([990, 9, 500, 499]), seeded((4, 3, 16, 16), 402).to(dev))
+    scale = float(tr.grads.abs().max())
+    assert float((got["grads"] - tr.grads.cpu()).abs().max()) <= 1e-4 * scale
+    tr.optimizer_step()
+    big = tr.grads.cpu().abs() > 1e-3 * scale          # Adam's first step is sign-like: compare where the gradient is not rounding noise
+    assert float((got["params1"] - tr.params.cpu())[big].abs().max()) <= 1e-6

@@ -12,7 +12,8 @@ from .restoration import DiffusiveRestoration, torchPSNR
 from .sampling import get_beta_schedule, compute_alpha, overlapping_grid_indices, ddim_sample
 from .datasets import RainDrop, RainDropDataset
 from .imageio import AsyncImageWriter
+from .training import Trainer
 
 __all__ = ["WaveletTransform", "DiffusionUNet", "DenoisingDiffusion_Wavelet", "DiffusiveRestoration",
            "data_transform", "inverse_data_transform", "torchPSNR", "get_beta_schedule", "compute_alpha",
-           "overlapping_grid_indices", "ddim_sample", "HFRM", "RainDrop", "RainDropDataset", "AsyncImageWriter"]
+           "overlapping_grid_indices", "ddim_sample", "HFRM", "RainDrop", "RainDropDataset", "AsyncImageWriter", "Trainer"]

@@ -105,8 +105,65 @@ class DenoisingDiffusion_Wavelet(object):
         self.model.pack_weights(force=True)
         print("=> loaded checkpoint '{}' (epoch {}, step {})".format(load_path, self.start_epoch, self.step))
 
-    def train(self, DATASET):
-        raise NotImplementedError("training is outside the accelerated sampling path (SURVEY.md §8f-3)")
+    # ---- training (ddm_wavelet.py:200-292) -----------------------------------------------------------------------
+    def make_trainer(self, **kw):
+        """The training state of this model on the HIP library (wavedm_amd.training.Trainer), initialised from the current weights."""
+        from .training import Trainer
+        tr = Trainer(self.config, device=self.device, dtype=kw.pop("dtype", None), **kw)
+        tr.load_state_dict(self.model.state_dict())
+        if self.ema_shadow is not None:
+            for k in tr.layout:
+                if k in self.ema_shadow:
+                    tr._view(tr.ema, k).copy_(self.ema_shadow[k].to(self.device))
+        tr.step = self.step
+        self.trainer = tr
+        return tr
+
+    def assemble_training_sample(self, x):
+        """x (n, 6, H, W) in [0,1] = [degraded | ground truth] crops -> the 96-channel wavelet-domain sample of ddm_wavelet.py:218-243
+        (`use_other_channels` and `use_gt_in_train` as in raindrop_wavelet.yml): [DWT(input) 48 | DWT(gt) LL 3 | DWT(gt) bands 3..47]."""
+        m = self.config.model
+        if not (m.use_other_channels and getattr(m, "use_gt_in_train", True)):
+            raise NotImplementedError("only the use_other_channels / use_gt_in_train branch of raindrop_wavelet.yml is built")
+        x = data_transform(x.to(self.device).float())
+        cond = self.wavelet_dec(x[:, :3].contiguous())
+        gt = self.wavelet_dec(x[:, 3:].contiguous())
+        return torch.cat([cond, gt[:, :m.pred_channels], gt[:, m.other_channels_begin:]], dim=1).contiguous()
+
+    def train_step(self, x, group=None):
+        """One iteration of the reference's loop body (:208-272) on a batch of crops x (n, 6, p, p): DWT, q-sample with antithetic
+        timesteps, loss, backward, gradient all-reduce, Adam, EMA.  Returns the loss as a device tensor."""
+        tr = getattr(self, "trainer", None) or self.make_trainer()
+        x = x.flatten(start_dim=0, end_dim=1) if x.ndim == 5 else x
+        loss = tr.train_step(self.assemble_training_sample(x), group=group)
+        self.step = tr.step
+        return loss
+
+    def sync_from_trainer(self, ema=False):
+        """Copy the trained (or EMA) weights back into the inference model."""
+        sd = self.trainer.ema_state_dict() if ema else self.trainer.state_dict()
+        self.model.load_state_dict(sd, strict=True)
+        self.model.pack_weights(force=True)
+
+    def train(self, DATASET, max_steps=None):
+        """ddm_wavelet.py:200-292 without the periodic validation restore: epochs over DATASET.get_loaders()[0], a checkpoint in the
+        reference's format every `training.snapshot_freq` steps.  `max_steps` bounds the run (tests, benchmarks)."""
+        import torch.distributed as dist
+        train_loader, _ = DATASET.get_loaders()
+        tr = getattr(self, "trainer", None) or self.make_trainer()
+        npix = self.config.model.pred_channels * self.config.data.image_size ** 2
+        rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        for epoch in range(self.start_epoch, self.config.training.n_epochs):
+            for i, (x, y, total) in enumerate(train_loader):
+                loss = self.train_step(x)
+                if self.step % 10 == 0 and rank0:
+                    print(f"step: {self.step}, loss: {float(loss)}, loss mean: {float(loss) / npix}")
+                if rank0 and (self.step % self.config.training.snapshot_freq == 0 or self.step == 1):
+                    path = os.path.join(self.config.data.data_dir, "ckpts", f"{self.config.data.dataset}_epoch{epoch + 1}_ddpm.pth.tar")
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    tr.save_checkpoint(path, epoch=epoch + 1)
+                if max_steps is not None and self.step >= max_steps:
+                    return
 
     # ---- sampling ----------------------------------------------------------------------------------
     def sample_image(self, x_cond, x, x_other=None, last=True, patch_locs=None, patch_size=None, total=None,
