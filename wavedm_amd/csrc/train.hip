@@ -15,10 +15,11 @@ namespace wdm {
 
 static inline int nblk(long long n, int bs) { long long g = (n + bs - 1) / bs; return (int)(g > 16384 ? 16384 : g); }
 
-// dst[b][c][k] (row length kp, k = oy*Wo + ox) = src[b][stride*oy + off_y][stride*ox + off_x][c_off + c]  (0 outside the map / past Ho*Wo)
+// dst[b][c][k] (row length kp, k = oy*Wo + ox; image stride dst_img elements) = src[b][stride*oy + off_y][stride*ox + off_x][c]
+// (0 outside the map / past Ho*Wo)
 template <typename T>
-__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int c_off, int C, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
-                                                       T* __restrict__ dst, int kp, long long total) {
+__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int C, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
+                                                       T* __restrict__ dst, long long dst_img, int kp, long long total) {
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(id % kp);
         const int c = (int)((id / kp) % C);
@@ -27,9 +28,9 @@ __global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src
         if (k < Ho * Wo) {
             const int oy = k / Wo, ox = k - oy * Wo;
             const int y = stride * oy + off_y, x = stride * ox + off_x;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = TI<T>::ld(src, ((b * H + y) * W + x) * xs + c_off + c);
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = TI<T>::ld(src, ((b * H + y) * W + x) * xs + c);
         }
-        TI<T>::st(dst, id, v);
+        TI<T>::st(dst, b * dst_img + (long long)c * kp + k, v);
     }
 }
 // grad[co][ci][tap] (OIHW f32) (+)= sum_b partial[tap][b][co][ci]   (rows_g rows per image in the partial buffer)
@@ -191,12 +192,10 @@ static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
 template <typename T>
 static void gather_t(hipStream_t s, const void* src, int xs, int c_off, int C, int B, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x, void* dst,
                      int rows_per_img, int kp) {
-    // dst image stride is rows_per_img * kp (rows past C stay as they are: the buffer is zeroed once by the caller)
-    for (int b = 0; b < B; ++b) {      // one launch per image keeps the index math 32-bit and the image stride free
-        const long long total = (long long)C * kp;
-        hipLaunchKernelGGL(gather_t_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)src + (long long)b * H * W * xs, xs, c_off, C, H, W, Ho, Wo, stride,
-                           off_y, off_x, (T*)dst + (long long)b * rows_per_img * kp, kp, total);
-    }
+    // dst image stride is rows_per_img * kp (rows past C stay as they are: the buffer is zeroed once by the caller where that matters)
+    const long long total = (long long)B * C * kp;
+    hipLaunchKernelGGL(gather_t_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)src + c_off, xs, C, H, W, Ho, Wo, stride, off_y, off_x, (T*)dst,
+                       (long long)rows_per_img * kp, kp, total);
 }
 #define BY_DTYPE(dtype, FN, ...) do { if ((dtype) == WDM_BF16) FN<__bf16>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
@@ -305,18 +304,64 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         s0 = &up0;
     }
     (void)up1; (void)t_up1;
+    const bool shifted = (mode == MODE_S1 || mode == MODE_UPS);
+    int rc = WDM_OK;
+    if (shifted) {
+        // 3x3 stride 1: ONE transposed image per dx column on a grid of (H + 2) rows x Wq columns (Wq = W rounded up to 8, so that a
+        // dy tap is a 16-byte aligned shift of +-Wq elements): aT_dx[ci][(y+1) Wq + x] = a[y][x + dx - 1], dyT on the same grid with
+        // zero border rows / columns -- 4 gathers + 9 GEMMs instead of 10 gathers.  Where a shifted read leaves its row the dyT factor
+        // is a border zero (operands are finite activations), so the neighbouring row's data is harmless; the buffer ends get zeroed margins.
+        const int Wq = (int)align_up((size_t)W, 8), Hq = H + 2;
+        const int kq = (int)align_up((size_t)Hq * Wq, kalign(c.dtype));
+        const size_t a_elems = (size_t)c.B * cin * kq;
+        void* dyT = c.ar->alloc((size_t)c.B * rows_g * kq * es);
+        char* aT3 = (char*)c.ar->alloc((3 * a_elems + 2 * (size_t)Wq) * es);
+        float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
+        if (!dyT || !aT3 || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
+        if (!c.dry) {
+            WDM_HIP(hipMemsetAsync(dyT, 0, (size_t)c.B * rows_g * kq * es, c.s));
+            WDM_HIP(hipMemsetAsync(aT3, 0, (size_t)Wq * es, c.s));
+            WDM_HIP(hipMemsetAsync(aT3 + ((size_t)Wq + 3 * a_elems) * es, 0, (size_t)Wq * es, c.s));
+            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq);
+            for (int dx = 0; dx < 3; ++dx) {
+                char* dst = aT3 + ((size_t)Wq + dx * a_elems) * es;
+                BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq);
+                if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst + (size_t)s0->C * kq * es, cin, kq);
+            }
+            for (int tap = 0; tap < 9 && rc == WDM_OK; ++tap) {
+                const int ty = tap / 3, tx = tap % 3;
+                ConvArgs a{};
+                a.x0 = dyT; a.C0 = kq; a.xs0 = kq; a.C1 = 0;
+                a.B = c.B; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
+                a.Cin = kq; a.Cout = cin;
+                a.w = aT3 + ((size_t)Wq + tx * a_elems) * es + (long long)(ty - 1) * Wq * (long long)es;
+                a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kq; a.w_row_stride = kq; a.w_rows = cin;
+                a.w_bytes = (unsigned)((size_t)cin * kq * es);
+                a.alpha = 1.f;
+                a.y = part + (size_t)tap * c.B * rows_g * cin; a.y_mode = Y_NHWC_F32; a.y_s = cin;
+                rc = launch_conv(a, MODE_P1, c.dtype, c.s);
+            }
+            if (rc == WDM_OK) {
+                const long long total = (long long)kk * cout * cin;
+                hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, c.B, rows_g, cout, cin, dw, accumulate ? 1 : 0);
+                WDM_HIP(hipGetLastError());
+            }
+        }
+        c.ar->free(part); c.ar->free(aT3); c.ar->free(dyT);
+        if (t_up0) c.ar->free(t_up0);
+        return rc;
+    }
     void* dyT = c.ar->alloc((size_t)c.B * rows_g * kp * es);
     void* aT = c.ar->alloc((size_t)c.B * cin * kp * es);
     float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
     if (!dyT || !aT || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
-    int rc = WDM_OK;
     if (!c.dry) {
         WDM_HIP(hipMemsetAsync(dyT, 0, (size_t)c.B * rows_g * kp * es, c.s));
         BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp);
         const int stride = mode == MODE_S2 ? 2 : 1;
         for (int tap = 0; tap < kk && rc == WDM_OK; ++tap) {
             const int ty = tap / k, tx = tap % k;
-            const int oy = mode == MODE_P1 ? 0 : (mode == MODE_S2 ? ty : ty - 1), ox = mode == MODE_P1 ? 0 : (mode == MODE_S2 ? tx : tx - 1);
+            const int oy = mode == MODE_P1 ? 0 : ty, ox = mode == MODE_P1 ? 0 : tx;      // Downsample: pad(0,1,0,1), stride 2
             BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Ho, Wo, stride, oy, ox, aT, cin, kp);
             if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Ho, Wo, stride, oy, ox, (char*)aT + (size_t)s0->C * kp * es, cin, kp);
             ConvArgs a{};
@@ -331,7 +376,6 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         }
         if (rc == WDM_OK) {
             const long long total = (long long)kk * cout * cin;
-            // partial rows per image = rows_g: compact view for the reduction
             hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, c.B, rows_g, cout, cin, dw, accumulate ? 1 : 0);
             WDM_HIP(hipGetLastError());
         }
