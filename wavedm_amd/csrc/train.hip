@@ -47,21 +47,31 @@ __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restri
         grad[o] = accumulate ? grad[o] + s : s;
     }
 }
-// out[g][c] (+)= sum over the rows of group g of x[row][c]; rows_per_group rows per group (bias grad: one group; temb grad: one per image)
+// out[g][c] (+)= sum over the rows of group g of x[row][c]; rows_per_group rows per group (bias grad: one group; temb grad: one per image).
+// Two stages, both in a fixed order: blocks of 64 channels x 4 row slices sum a chunk of rows each, then the chunks are added up.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int xs, int C, long long rows_per_group, float* __restrict__ out, int out_ld, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int xs, int C, long long rows_per_group, int chunk_rows, int nchunks,
+                                                          float* __restrict__ part) {
     __shared__ float red[256];
-    const int g = blockIdx.y;
+    const int g = blockIdx.y, ch = blockIdx.z;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const long long r0 = (long long)ch * chunk_rows, r1 = r0 + chunk_rows < rows_per_group ? r0 + chunk_rows : rows_per_group;
     float s = 0.f;
     if (c < C)
-        for (long long r = sl; r < rows_per_group; r += 4) s += TI<T>::ld(x, (g * rows_per_group + r) * xs + c);
+        for (long long r = r0 + sl; r < r1; r += 4) s += TI<T>::ld(x, (g * rows_per_group + r) * xs + c);
     red[threadIdx.x] = s;
     __syncthreads();
-    if (sl == 0 && c < C) {
-        const float t = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        out[(long long)g * out_ld + c] = accumulate ? out[(long long)g * out_ld + c] + t : t;
-    }
+    if (sl == 0 && c < C) part[((long long)g * nchunks + ch) * C + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int C, int nchunks, int groups, float* __restrict__ out, int out_ld,
+                                                           int accumulate) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= groups * C) return;
+    const int g = id / C, c = id - g * C;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += part[((long long)g * nchunks + k) * C + c];
+    const long long o = (long long)g * out_ld + c;
+    out[o] = accumulate ? out[o] + s : s;
 }
 // Downsample dgrad helper: z[b][2oy+1][2ox+1][c] = dy[b][oy][ox][c], zero elsewhere (z is H x W, dy is H/2 x W/2)
 template <typename T>
@@ -215,8 +225,14 @@ template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, in
 template <typename T> static void l_pad_channels(hipStream_t s, const void* x, int C, int Cp, void* y, long long total) {
     hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)x, C, Cp, (T*)y, total);
 }
-template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc, int out_ld = 0) {
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 63) / 64, groups), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, out, out_ld ? out_ld : C, acc);
+// needs a scratch buffer of groups * nchunks * C floats
+static inline int colsum_chunks(long long rows_per_group) { long long n = (rows_per_group + 255) / 256; return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n)); }
+template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc, int out_ld,
+                                           float* scratch) {
+    const int nchunks = colsum_chunks(rows_per_group);
+    const int chunk_rows = (int)((rows_per_group + nchunks - 1) / nchunks);
+    hipLaunchKernelGGL(colsum_part_kernel<T>, dim3((C + 63) / 64, groups, nchunks), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, chunk_rows, nchunks, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, s, scratch, C, nchunks, groups, out, out_ld ? out_ld : C, acc);
 }
 
 // ---- dgrad: dx (+)= conv^T(dy).  (H, W) is the forward INPUT map; dy is dense NHWC [B][Ho][Wo][cout]; dx dense [B][H][W][cin].
@@ -387,25 +403,30 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
 
 // db[c] (+)= sum over all rows of dy;  per_image: out[b][c] = sum over the image's rows (temb gradient)
 int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, int out_ld) {
-    if (c.dry) return WDM_OK;
     const long long rows = (long long)dy.H * dy.W * (per_image ? 1 : c.B);
-    BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, per_image ? c.B : 1, out, accumulate ? 1 : 0, out_ld);
-    WDM_HIP(hipGetLastError());
+    const int groups = per_image ? c.B : 1;
+    float* scratch = (float*)c.ar->alloc((size_t)groups * colsum_chunks(rows) * dy.C * sizeof(float));
+    if (!scratch) WDM_FAIL(WDM_ENOMEM, "workspace too small (column sums)");
+    if (!c.dry) {
+        BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, groups, out, accumulate ? 1 : 0, out_ld, scratch);
+        WDM_HIP(hipGetLastError());
+    }
+    c.ar->free(scratch);
     return WDM_OK;
 }
-
 
 // GroupNorm (+SiLU) backward over [x0 | x1]; mean_rstd from the forward's finalize.  dgamma / dbeta (+)= batch sums.
 int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
                     bool acc1, float* dgamma, float* dbeta, bool acc_param) {
     const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
-    float* part = (float*)c.ar->alloc((size_t)2 * c.B * C * sizeof(float));
+    float* part = (float*)c.ar->alloc(((size_t)2 * c.B * C + (size_t)colsum_chunks(c.B) * C) * sizeof(float));
     if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm backward)");
     if (!c.dry) {
         BY_DTYPE(c.dtype, l_gn_act_bwd, c.s, c.B, x0.p, x0.xs, x0.C, x1 ? x1->p : x0.p, x1 ? x1->xs : 0, C, HW, dy.p, nw.g, nw.b, mean_rstd, silu, dx0, acc0 ? 1 : 0,
                  x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C);
-        l_colsum<float>(c.s, part, C, C, c.B, 1, dgamma, acc_param ? 1 : 0);
-        l_colsum<float>(c.s, part + (size_t)c.B * C, C, C, c.B, 1, dbeta, acc_param ? 1 : 0);
+        float* sc2 = part + (size_t)2 * c.B * C;
+        l_colsum<float>(c.s, part, C, C, c.B, 1, dgamma, acc_param ? 1 : 0, 0, sc2);
+        l_colsum<float>(c.s, part + (size_t)c.B * C, C, C, c.B, 1, dbeta, acc_param ? 1 : 0, 0, sc2);
         WDM_HIP(hipGetLastError());
     }
     c.ar->free(part);
@@ -419,7 +440,7 @@ int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst) {
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
-void l_colsum_f32(hipStream_t s, const float* x, int C, int rows, float* out) { l_colsum<float>(s, x, C, C, rows, 1, out, 0); }
+void l_colsum_f32(hipStream_t s, const float* x, int C, int rows, float* out, float* scratch) { l_colsum<float>(s, x, C, C, rows, 1, out, 0, 0, scratch); }   // scratch: colsum_chunks(rows) * C floats
 
 }  // namespace wdm
 

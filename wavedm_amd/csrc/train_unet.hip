@@ -110,12 +110,22 @@ __global__ void lin_bwd_w_kernel(const float* __restrict__ dy, const float* __re
     for (int i = 0; i < n; ++i) s += dy[(long long)i * o + oo] * x[(long long)i * k + kk];
     dW[id] = s;
 }
-__global__ void lin_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int n, int o, int k, float* __restrict__ dx) {
+// two stages (64 slices of the o range, then their sum in slice order) so that the [rows][4ch] projection matrix is read by many blocks
+__global__ void lin_bwd_x_part_kernel(const float* __restrict__ dy, const float* __restrict__ W, int n, int o, int k, float* __restrict__ part) {
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (long long)n * k) return;
     const int kk = (int)(id % k), nn = (int)(id / k);
+    const int sl = blockIdx.y, per = (o + 63) / 64;
+    const int o0 = sl * per, o1 = o0 + per < o ? o0 + per : o;
     float s = 0.f;
-    for (int i = 0; i < o; ++i) s += dy[(long long)nn * o + i] * W[(long long)i * k + kk];
+    for (int i = o0; i < o1; ++i) s += dy[(long long)nn * o + i] * W[(long long)i * k + kk];
+    part[(long long)sl * n * k + id] = s;
+}
+__global__ void lin_bwd_x_final_kernel(const float* __restrict__ part, long long nk, float* __restrict__ dx) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nk) return;
+    float s = 0.f;
+    for (int sl = 0; sl < 64; ++sl) s += part[(long long)sl * nk + id];
     dx[id] = s;
 }
 // torch.optim.Adam (amsgrad = False) + EMAHelper.update, one pass over the flat buffers
@@ -157,7 +167,7 @@ template <typename T> static void l_loss(hipStream_t s, const float* out, const 
 }
 // transposed copy used by the attention backward: dst[b][c][n] = src[b][n][c]   (train.hip's gather with stride 1, offset 0)
 int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst);
-void l_colsum_f32(hipStream_t s, const float* x, int C, int rows, float* out);
+void l_colsum_f32(hipStream_t s, const float* x, int C, int rows, float* out, float* scratch);
 
 #define BYT(DT, FN, ...) do { if ((DT) == WDM_BF16) FN<__bf16>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
@@ -522,18 +532,20 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     // ---- temb MLP backward
     {
         const long long n4 = (long long)B * temb_ch;
-        float *d_s1 = af(n4), *d_t1 = af(n4), *d_t0 = af(n4), *d_pre0 = af(n4);
-        if (!d_s1 || !d_t1 || !d_t0 || !d_pre0) WDM_FAIL(WDM_ENOMEM, "training workspace too small (temb backward)");
+        float *d_s1 = af(n4), *d_t1 = af(n4), *d_t0 = af(n4), *d_pre0 = af(n4), *csc = af((size_t)4 * temb_rows), *xpart = af((size_t)64 * n4);
+        if (!d_s1 || !d_t1 || !d_t0 || !d_pre0 || !csc || !xpart) WDM_FAIL(WDM_ENOMEM, "training workspace too small (temb backward)");
         hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_rows * temb_ch, 256)), dim3(256), 0, cc.s, d_temb_all, s1, B, temb_rows, temb_ch, G + tw);
-        l_colsum_f32(cc.s, d_temb_all, temb_rows, B, G + tb);
-        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, d_temb_all, P + tw, B, temb_rows, temb_ch, d_s1);
+        l_colsum_f32(cc.s, d_temb_all, temb_rows, B, G + tb, csc);
+        hipLaunchKernelGGL(lin_bwd_x_part_kernel, dim3(nbu(n4, 256), 64), dim3(256), 0, cc.s, d_temb_all, P + tw, B, temb_rows, temb_ch, xpart);
+        hipLaunchKernelGGL(lin_bwd_x_final_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, xpart, n4, d_s1);
         hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, t1, d_s1, d_t1, n4);
         hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_ch * temb_ch, 256)), dim3(256), 0, cc.s, d_t1, t0, B, temb_ch, temb_ch, G + d1w);
-        l_colsum_f32(cc.s, d_t1, temb_ch, B, G + d1b);
-        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, d_t1, P + d1w, B, temb_ch, temb_ch, d_t0);
+        l_colsum_f32(cc.s, d_t1, temb_ch, B, G + d1b, csc);
+        hipLaunchKernelGGL(lin_bwd_x_part_kernel, dim3(nbu(n4, 256), 64), dim3(256), 0, cc.s, d_t1, P + d1w, B, temb_ch, temb_ch, xpart);
+        hipLaunchKernelGGL(lin_bwd_x_final_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, xpart, n4, d_t0);
         hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(nbu(n4, 256)), dim3(256), 0, cc.s, pre0, d_t0, d_pre0, n4);
         hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(nbu((long long)temb_ch * cfg.ch, 256)), dim3(256), 0, cc.s, d_pre0, emb, B, temb_ch, cfg.ch, G + d0w);
-        l_colsum_f32(cc.s, d_pre0, temb_ch, B, G + d0b);
+        l_colsum_f32(cc.s, d_pre0, temb_ch, B, G + d0b, csc);
         WDM_HIP(hipGetLastError());
     }
     acts.clear(); tape.clear();
