@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwavedm_hip.so")
 
 WDM_F32, WDM_BF16 = 0, 1
+WDM_OK, WDM_EINVAL, WDM_ENOMEM, WDM_EHIP, WDM_ESTATE, WDM_ENOTFOUND = 0, -1, -2, -3, -4, -5
 DTYPES = {"f32": WDM_F32, "fp32": WDM_F32, "float32": WDM_F32, "bf16": WDM_BF16, "bfloat16": WDM_BF16}
 
 _lib = None

@@ -110,13 +110,24 @@ class Trainer:
         tf = t.float().contiguous()
         out = torch.empty(B, int(self.config.model.out_ch), R, R, device=self.device) if return_output else None
         with torch.cuda.device(self.device):
-            if self._ws is None or self._ws[0] < B:
-                # saved activations + gradients + operand transposes: sized generously from the batch (288 GB of HBM)
-                per_img = 96 * R * R * 4 * 400
-                self._ws = (B, torch.empty(B * per_img + (1 << 28), dtype=torch.uint8, device=self.device))
-            ws = self._ws[1]
-            _lib.check(_lib.lib().wdm_trainer_step(self._t, _lib.ptr(x0), _lib.ptr(tf), _lib.ptr(sa), _lib.ptr(s1m), _lib.ptr(e), B, self._c_t0, _lib.ptr(self._loss),
-                                                   _lib.ptr(out) if out is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+            # workspace = every saved activation + its gradient + operand transposes of the largest layer.  It is sized from the batch
+            # (288 GB of HBM: generosity is cheap) and doubled on demand: the library reports exhaustion as an error, never overruns.
+            need = B * 96 * R * R * 4 * 160 + (1 << 28)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            for attempt in range(4):
+                ws = self._ws
+                rc = _lib.lib().wdm_trainer_step(self._t, _lib.ptr(x0), _lib.ptr(tf), _lib.ptr(sa), _lib.ptr(s1m), _lib.ptr(e), B, self._c_t0, _lib.ptr(self._loss),
+                                                 _lib.ptr(out) if out is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                if rc == _lib.WDM_ENOMEM and attempt < 3:
+                    torch.cuda.synchronize(self.device)
+                    n = ws.numel() * 2
+                    self._ws = ws = None
+                    self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+                    continue
+                _lib.check(rc)
+                break
         return (self._loss[0], out) if return_output else self._loss[0]
 
     def allreduce_grads(self, group=None):
