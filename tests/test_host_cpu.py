@@ -120,3 +120,26 @@ def test_raindrop_dataset_matches_reference_golden(golden, tmp_path):
     dt = RainDropDataset(dir=str(tmp_path / "raindrop" / "raindrop_test"), patch_size=64, n=4, parse_patches=True)
     x, img_id, total = dt[0]
     assert tuple(x.shape) == (4, 6, 64, 64) and tuple(total.shape) == (4, 3, 480, 720)
+
+
+def test_trainer_param_table_on_host():
+    """wdm_trainer_param_info needs no GPU: every state_dict entry of the reference once, offsets tile the flat buffer exactly."""
+    from wavedm_amd.unet import _make_config
+    L = _lib.lib()
+    for cfg in (P.reduced_config(), P.raindrop_wavelet_config()):
+        c = _make_config(cfg, _lib.WDM_BF16)
+        t = C.c_void_p()
+        _lib.check(L.wdm_trainer_create(None, C.byref(c), C.byref(t)))
+        name, ndim, shape, off = C.c_char_p(), C.c_int(), (C.c_int64 * 4)(), C.c_int64()
+        want = P.unet_param_shapes(cfg)
+        seen, spans = {}, []
+        for i in range(L.wdm_trainer_num_params(t)):
+            _lib.check(L.wdm_trainer_param_info(t, i, C.byref(name), C.byref(ndim), C.byref(shape), C.byref(off)))
+            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            seen[name.value.decode()] = shp
+            spans.append((int(off.value), int(np.prod(shp))))
+        assert seen == {k: tuple(v) for k, v in want.items()}
+        spans.sort()
+        assert spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:]))
+        assert spans[-1][0] + spans[-1][1] == int(L.wdm_trainer_num_floats(t)) == sum(int(np.prod(v)) for v in want.values())
+        L.wdm_trainer_destroy(t)
