@@ -143,17 +143,18 @@ __global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x
                                                          const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean_rstd, int silu, T* __restrict__ dx0, int acc0, T* __restrict__ dx1, int acc1,
                                                          float* __restrict__ dgam_part, float* __restrict__ dbet_part) {
-    __shared__ float red[2][4];
+    __shared__ float wsum[2][4];
     __shared__ float msum[2];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int gw = C / 32, cg0 = g * gw, C1 = C - C0;
     const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
-    float Sa = 0.f, Sb = 0.f;                       // thread 0 only
-    for (int ci = 0; ci < gw; ++ci) {
+    // phase 1: wave w owns channels w, w+4, ... of the group: per-channel sums over the image's pixels by shuffles only
+    float Sa = 0.f, Sb = 0.f;                       // lane 0 of each wave
+    for (int ci = wv; ci < gw; ci += 4) {
         const int c = cg0 + ci;
         const float gm = gamma[c], bt = beta[c];
         float sg = 0.f, sb = 0.f;
-        for (int p = tid; p < HW; p += 256) {
+        for (int p = lane; p < HW; p += 64) {
             const long long bp = (long long)b * HW + p;
             const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
             const float xh = (xv - mean) * rstd;
@@ -163,15 +164,14 @@ __global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
-        if (lane == 0) { red[0][wv] = sg; red[1][wv] = sb; }
-        __syncthreads();
-        if (tid == 0) {
-            const float tg = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), tb = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-            dgam_part[(long long)b * C + c] = tg; dbet_part[(long long)b * C + c] = tb;
-            Sa += gm * tb; Sb += gm * tg;
+        if (lane == 0) {
+            dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
+            Sa += gm * sb; Sb += gm * sg;
         }
-        __syncthreads();
     }
+    if (lane == 0) { wsum[0][wv] = Sa; wsum[1][wv] = Sb; }
+    __syncthreads();
+    if (tid == 0) { Sa = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]); Sb = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]); }
     if (tid == 0) { const float N = (float)gw * (float)HW; msum[0] = Sa / N; msum[1] = Sb / N; }
     __syncthreads();
     const float ma = msum[0], mb = msum[1];
