@@ -87,7 +87,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     }
 
     constexpr unsigned OOB = 0xFFFF0000u;
-    const int wimg = (a.w_img_stride != 0) ? img0 : 0;
     // ---- per-lane source offsets of this wave's chunks (loop-invariant; the K step is a scalar offset)
     unsigned a_v0[A_CPW], a_v1[A_CPW], b_v[B_CPW];
 #pragma unroll
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         const int img_g = img0 + img;
         const int iy = oy0 + r / TW, ix = ox0 + r % TW;
         const bool ok = img_g < a.B && iy < a.Hin && ix < a.Win;
-        const unsigned gp = (unsigned)((img_g * a.Hin + iy) * a.Win + ix);
+        const unsigned gp = (unsigned)((conv_x_img(a, img_g) * a.Hin + iy) * a.Win + ix);
         a_v0[j] = ok ? gp * (unsigned)(a.xs0 * 2) + (unsigned)(u * 16) : OOB;
         a_v1[j] = ok ? gp * (unsigned)(a.xs1 * 2) + (unsigned)(u * 16) : OOB;
     }
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         return i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
     };
     const i32x4 q_x0 = make_q(a.x0, a.x0_bytes), q_x1 = make_q(a.x1 ? a.x1 : a.x0, a.x1_bytes);
-    const i32x4 q_w = make_q((const T*)a.w + (long long)wimg * a.w_img_stride, a.w_bytes);
+    const i32x4 q_w = make_q((const T*)a.w + conv_w_img_offset(a, img0), a.w_bytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto dma16 = [&](const i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
         unsigned keep;

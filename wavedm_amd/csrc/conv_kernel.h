@@ -92,7 +92,21 @@ struct ConvArgs {
     int sw_row_stride, sw_rows;
     unsigned sx0_bytes, sx1_bytes, sw_bytes;
     const float* sbias;    // [Cout] added like bias
+    // batched-GEMM addressing for the training wgrad (1x1 mode, per-image weights): image i = tap * img_mod + b reads the input of
+    // image b (x0 is shared by the taps) and the weight matrix of image b displaced by the tap:
+    //   w + b * w_img_stride + (tap % 3) * w_tx_stride + (tap / 3 - 1) * w_ty_stride        (img_mod == 0: off)
+    int img_mod;
+    long long w_tx_stride, w_ty_stride;
 };
+
+// element offset of the weight matrix image `img` reads, and the image whose input it reads
+__host__ __device__ inline long long conv_w_img_offset(const ConvArgs& a, int img) {
+    if (a.w_img_stride == 0) return 0;
+    if (a.img_mod == 0) return (long long)img * a.w_img_stride;
+    const int tap = img / a.img_mod, b = img - tap * a.img_mod;
+    return (long long)b * a.w_img_stride + (long long)(tap % 3) * a.w_tx_stride + (long long)(tap / 3 - 1) * a.w_ty_stride;
+}
+__host__ __device__ inline int conv_x_img(const ConvArgs& a, int img) { return a.img_mod ? img % a.img_mod : img; }
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -512,7 +526,6 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
     const int unit = tid & (NU - 1);
     const int nchunks = a.Cin / BK;                                   // slabs
     const int nstages = (MODE == MODE_P1) ? (nchunks + NSUB - 1) / NSUB : nchunks;
-    const int wimg = (a.w_img_stride != 0) ? img0 : 0;
     constexpr int ES = (int)sizeof(T);
     constexpr int RPI_ = C::NTHREADS / NU;                            // rows (pixels / weight rows) covered per item index
 
@@ -523,7 +536,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
     constexpr unsigned OOB = 0xFFFF0000u;      // >= num_records of any tensor (host asserts tensors < 4 GB - 64 KB)
     const __amdgpu_buffer_rsrc_t r_x0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, a.x0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x1 ? a.x1 : a.x0), 0, a.x1_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.w + (long long)wimg * a.w_img_stride), 0,
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.w + conv_w_img_offset(a, img0)), 0,
                                                                         a.w_bytes, 0x00020000);
     unsigned a_v0[NI][A_IPI], a_v1[NI][A_IPI];   // byte offset of (pixel, unit) in x0 / x1
     int a_l[NI][A_IPI];                          // LDS byte offset of the item (sub-plane included)
@@ -539,7 +552,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
             const int hy = q / PW, hx = q - hy * PW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = (pq < NSUBA * NPIX) && (img_g < a.B) && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            const unsigned gp = (unsigned)((img_g * a.Hin + iy) * a.Win + ix);
+            const unsigned gp = (unsigned)((conv_x_img(a, img_g) * a.Hin + iy) * a.Win + ix);
             a_v0[im][i] = ok ? gp * (unsigned)(a.xs0 * ES) + (unsigned)(unit * 16) : OOB;
             a_v1[im][i] = ok ? gp * (unsigned)(a.xs1 * ES) + (unsigned)(unit * 16) : OOB;
             a_l[im][i] = sub * (PLANE * 64) + lds_off(im * PLANE_IMG + hy * RS + hx, unit);

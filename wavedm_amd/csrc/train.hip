@@ -344,17 +344,17 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
                 BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq);
                 if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst + (size_t)s0->C * kq * es, cin, kq);
             }
-            for (int tap = 0; tap < 9 && rc == WDM_OK; ++tap) {
-                const int ty = tap / 3, tx = tap % 3;
+            {   // the nine taps as ONE batched GEMM: image i = tap * B + b reads dyT[b] and aT_{tap % 3}[b] shifted by (tap / 3 - 1) rows
                 ConvArgs a{};
                 a.x0 = dyT; a.C0 = kq; a.xs0 = kq; a.C1 = 0;
-                a.B = c.B; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
+                a.B = 9 * c.B; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
                 a.Cin = kq; a.Cout = cin;
-                a.w = aT3 + ((size_t)Wq + tx * a_elems) * es + (long long)(ty - 1) * Wq * (long long)es;
+                a.w = aT3 + (size_t)Wq * es;
                 a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kq; a.w_row_stride = kq; a.w_rows = cin;
+                a.img_mod = c.B; a.w_tx_stride = (long long)a_elems; a.w_ty_stride = Wq;
                 a.w_bytes = (unsigned)((size_t)cin * kq * es);
                 a.alpha = 1.f;
-                a.y = part + (size_t)tap * c.B * rows_g * cin; a.y_mode = Y_NHWC_F32; a.y_s = cin;
+                a.y = part; a.y_mode = Y_NHWC_F32; a.y_s = cin;
                 rc = launch_conv(a, MODE_P1, c.dtype, c.s);
             }
             if (rc == WDM_OK) {
