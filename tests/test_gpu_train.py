@@ -219,3 +219,36 @@ def test_train_step_api_and_checkpoint_roundtrip(tmp_path):
     d2.load_ddm_ckpt(path, ema=True)
     ema = tr.ema_state_dict()
     assert all(torch.equal(p.detach().cpu(), ema[k].cpu()) for k, p in d2.model.named_parameters())
+
+
+def test_train_loop_on_synthetic_dataset(tmp_path):
+    """DenoisingDiffusion_Wavelet.train(DATASET): RainDrop training loader (random crops) -> DWT -> train steps -> checkpoint at step 1."""
+    import os
+    import random
+    from types import SimpleNamespace
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    from wavedm_amd.datasets import RainDrop
+    O.synthetic_raindrop_dir(str(tmp_path), seed=303, sizes=((200, 140), (180, 120)))
+    os.rename(tmp_path / "raindrop" / "raindrop_test", tmp_path / "raindrop" / "train")
+    for sub in ("input", "gt"):
+        os.makedirs(tmp_path / "raindrop" / "raindrop_test" / sub)
+    cfg = P.reduced_config()
+    cfg.device = dev()
+    cfg.data.data_dir, cfg.data.patch_size = str(tmp_path), 64
+    cfg.training = SimpleNamespace(patch_n=4, batch_size=1, n_epochs=2, snapshot_freq=1000)
+    cfg.optim = SimpleNamespace(lr=1e-3, eps=1e-8, weight_decay=0.0)
+    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4, world_size=1, rank=0)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="bf16")
+    d.model.load_state_dict(P.procedural_state_dict(cfg), strict=True)
+    random.seed(1)
+    torch.manual_seed(1)
+    d.train(RainDrop(args, cfg), max_steps=3)
+    assert d.step == 3
+    ck = tmp_path / "ckpts" / f"{cfg.data.dataset}_epoch1_ddpm.pth.tar"
+    assert ck.is_file()                                        # written at step 1 (ddm_wavelet.py:282)
+    saved = torch.load(ck, weights_only=False)
+    assert saved["step"] == 1 and set(saved["state_dict"]) == set(P.unet_param_shapes(cfg))
+    d.sync_from_trainer(ema=True)
+    x96 = seeded((1, 96, 16, 16), 40).to(dev())
+    assert bool(torch.isfinite(d.model(x96, torch.tensor([500.0]))).all())
