@@ -1,3 +1,4 @@
+# L2 hit-rate experiment ("XCD tile order variants"): TCC hit / miss counters for the tile-order variants of the main conv
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out/raw
