@@ -21,8 +21,12 @@ def test_two_ranks_match_single_process(tmp_path):
     import wavedm_amd
     out = tmp_path / "dist.pt"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sock:                      # a free rendezvous port on this box
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(HERE, "dist_worker.py"), str(out)]
+           "--master-port", str(port), os.path.join(HERE, "dist_worker.py"), str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out)
