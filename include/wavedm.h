@@ -110,8 +110,8 @@ typedef struct wdm_unet_config {
     int num_res_blocks;
     int n_attn_res;          /* len(model.attn_resolutions), <= 8 */
     int attn_resolutions[8];
-    int in_channels;         /* UNet input channels (96 for raindrop_wavelet.yml, unet.py:212) */
-    int out_ch;              /* 3 */
+    int in_channels;         /* UNet input channels (96 for raindrop_wavelet.yml, unet.py:212); any width >= 1: conv_in is zero-padded to a multiple of 32 */
+    int out_ch;              /* 3 (12 / 48 with data.use_window / data.wavelet_in_unet) */
     int resolution;          /* data.image_size */
     int resamp_with_conv;    /* must be 1 */
     int dtype;               /* WDM_BF16 (throughput) or WDM_F32 (parity mode) */

@@ -142,11 +142,37 @@ def upsample(sd, name, x):
     return conv(sd, name + ".conv", F.interpolate(x, scale_factor=2.0, mode="nearest"), padding=1)
 
 
-def unet_forward(sd, config, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-    """unet.py:346-395 with use_window / wavelet_in_unet off (raindrop_wavelet.yml).
+def to_win(x, p):                   # unet.py:309-314
+    B, C, H, W = x.shape
+    return x.view(B, C, p, H // p, p, W // p).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, -1, H // p, W // p)
 
-    x: (B, 96, R, R) = [x_cond 0:48 | x_t 48:51 | x_other 51:96], t: (n,) float, n in {1, B}.
+
+def win_back(x, p):                 # unet.py:316-321
+    B, C, H, W = x.shape
+    return x.view(B, C // (p ** 2), p, p, H, W).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, C // (p ** 2), H * p, W * p)
+
+
+def unet_forward(sd, config, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """unet.py:346-395, including the optional use_window / wavelet_in_unet re-arrangements (:347-350, :387-391; both off in
+    raindrop_wavelet.yml).
+
+    Default layout: x (B, 96, R, R) = [x_cond 0:48 | x_t 48:51 | x_other 51:96]; t: (n,) float, n in {1, B}.
     """
+    d = config.data
+    if getattr(d, "use_window", False):
+        p = d.window_size
+        x = torch.cat([to_win(x[:, :3], p), to_win(x[:, 3:], p)], dim=1)
+    if getattr(d, "wavelet_in_unet", False):
+        x = torch.cat([dwt_fwd(x[:, :3]), dwt_fwd(x[:, 3:])], dim=1)
+    h = _unet_core(sd, config, x, t)
+    if getattr(d, "use_window", False):
+        h = win_back(h, d.window_size)
+    if getattr(d, "wavelet_in_unet", False):
+        h = dwt_inv(h)
+    return h
+
+
+def _unet_core(sd, config, x, t):
     m = config.model
     ch, ch_mult = m.ch, tuple(m.ch_mult)
     nres, nrb, attn_res = len(ch_mult), m.num_res_blocks, list(m.attn_resolutions)
@@ -234,9 +260,9 @@ def overlap_count_mask(h, w, p, corners) -> torch.Tensor:
 
 def ddim_overlapping(sd, config, x, x_cond, x_other, corners, p, sampling_timesteps,
                      betas=None, model=None, chunk=8):
-    """ddm_wavelet.py:437-506 with eta=0, begin_from_noise=True, use_other=True.
+    """ddm_wavelet.py:437-506 with eta=0, begin_from_noise=True; use_other=False <=> x_other is None (:471-478).
 
-    x: (1,3,H,W) start noise, x_cond: (1,48,H,W), x_other: (1,45,H,W).
+    x: (1,3,H,W) start noise, x_cond: (1,48,H,W), x_other: (1,45,H,W) or None.
     Returns (xs, x0_preds) lists like the reference (len S+1 and S).
     `model(x96, t)` defaults to this file's `unet_forward`.
     The reference draws `randn_like` every step and multiplies it by c1 = 0: no effect on values.
@@ -260,9 +286,10 @@ def ddim_overlapping(sd, config, x, x_cond, x_other, corners, p, sampling_timest
             acc = torch.zeros_like(x)
             xt_p = torch.cat([xt[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
             xc_p = torch.cat([x_cond[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
-            xo_p = torch.cat([x_other[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
+            if x_other is not None:
+                xo_p = torch.cat([x_other[:, :, hi:hi + p, wi:wi + p] for (hi, wi) in corners], dim=0)
             for i in range(0, len(corners), chunk):
-                x96 = torch.cat([xc_p[i:i + chunk], xt_p[i:i + chunk], xo_p[i:i + chunk]], dim=1)
+                x96 = torch.cat([xc_p[i:i + chunk], xt_p[i:i + chunk]] + ([xo_p[i:i + chunk]] if x_other is not None else []), dim=1)
                 out = model(x96, t)
                 for idx, (hi, wi) in enumerate(corners[i:i + chunk]):
                     acc[0, :, hi:hi + p, wi:wi + p] += out[idx]
@@ -291,8 +318,8 @@ def ddim_batch(sd, config, x_T, x_cond, x_other, sampling_timesteps, betas=None,
             at, at_next = compute_alpha(betas, i_t), compute_alpha(betas, j_t)
             xt = xs[-1]
             et = torch.cat([unet_forward(sd, config,
-                                         torch.cat([x_cond[i:i + chunk], xt[i:i + chunk],
-                                                    x_other[i:i + chunk]], dim=1), t)
+                                         torch.cat([x_cond[i:i + chunk], xt[i:i + chunk]]
+                                                   + ([x_other[i:i + chunk]] if x_other is not None else []), dim=1), t)
                             for i in range(0, B, chunk)], dim=0)
             x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
             x0_preds.append(x0_t)

@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--only-hfrm", action="store_true", help="regenerate hfrm.npz only")
     ap.add_argument("--only-io", action="store_true", help="regenerate io.npz only")
     ap.add_argument("--only-train", action="store_true", help="regenerate train.npz only")
+    ap.add_argument("--only-variants", action="store_true", help="regenerate variants.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -213,6 +214,30 @@ def main():
         np.savez_compressed(out("train.npz"), **tr)
         torch.set_grad_enabled(False)
 
+    # ------------------------------------------------------------------ optional config branches
+    def golden_variants():
+        print("[variants]")
+        va = {}
+        for kind in P.VARIANTS:
+            c, shape = P.variant_config(kind)
+            c.device = torch.device("cpu")
+            sd_v = P.procedural_state_dict(c, seed=61)
+            net_v = RU.DiffusionUNet(c).eval()
+            # wavelet_in_unet: the model also holds its two frozen Haar (de)conv weights (models/unet.py:204-206); they stay as built
+            frozen = [k for k in net_v.state_dict().keys() if k.startswith("wavelet_")]
+            assert [k for k in net_v.state_dict().keys() if k not in frozen] == list(sd_v.keys()), kind
+            assert net_v.load_state_dict(sd_v, strict=False).unexpected_keys == []
+            for k in frozen:
+                va[kind + ":" + k] = net_v.state_dict()[k].numpy()
+            x = seeded(shape, 700)
+            y = net_v(x, torch.tensor([400.0, 30.0]))
+            check(f"unet variant {kind}", O.unet_forward(sd_v, c, x, torch.tensor([400.0, 30.0])), y)
+            va[kind] = y.numpy()
+        np.savez_compressed(out("variants.npz"), **va)
+
+    if args.only_variants:
+        golden_variants()
+        return
     if args.only_train:
         golden_train()
         return
@@ -225,6 +250,7 @@ def main():
     golden_hfrm()
     golden_io()
     golden_train()
+    golden_variants()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")

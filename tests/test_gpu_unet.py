@@ -193,6 +193,49 @@ def test_config4_fullres_stitch(dtype):
         assert float((outs[0].cpu() - want).abs().mean()) <= 2e-2
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["no_other", "window", "wavelet_in_unet"])
+def test_optional_unet_branches(golden, kind, dtype):
+    """the three optional branches of models/unet.py against the reference's own outputs."""
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    v = golden("variants.npz")
+    cfg, shape = P.variant_config(kind)
+    net = wavedm_amd.DiffusionUNet(cfg, dtype=dtype)
+    net.load_state_dict(P.procedural_state_dict(cfg, seed=61), strict=False)
+    net = net.cuda()
+    y = net(seeded(shape, 700).cuda(), torch.tensor([400.0, 30.0]))
+    assert tuple(y.shape) == v[kind].shape
+    assert rel_linf(y.cpu(), v[kind]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_sampler_without_other_channels(dtype):
+    """use_other=False (ddm_wavelet.py:471-478): the UNet input is [x_cond | x_t]; batched and stitched sampler vs the oracle."""
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import procedural as P
+    cfg, _ = P.variant_config("no_other")
+    sd = P.procedural_state_dict(cfg, seed=61)
+    d, _ = make_diffusion(cfg, dtype, 6)
+    d.model.load_state_dict(sd, strict=True)
+    rainy, x_T = P.synthetic_batch(2, patch_px=64)
+    xc_cpu = O.dwt_fwd(2 * rainy - 1)
+    xs_o, x0_o = O.ddim_batch(sd, cfg, x_T, xc_cpu, None, 6)
+    xc = d.wavelet_dec(2 * rainy.cuda() - 1)
+    xs, x0 = d.sample_image(xc, x_T.cuda(), x_other=None, last=False, patch_locs=[(0, 0)], patch_size=16, use_other=False)
+    assert rel_linf(xs[-1].cpu(), xs_o[-1]) <= TOL[dtype] and rel_linf(x0[-5].cpu(), x0_o[-5]) <= TOL[dtype]
+    # stitched: one 30x45 wavelet-domain image, 16x16 patches every 4
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(1, 3, 120, 180, generator=g)
+    xT = torch.randn(1, 3, 30, 45, generator=g)
+    xc_cpu = O.dwt_fwd(2 * img - 1)
+    corners = O.grid_corners(30, 45, 16, 4)
+    xs_o, _ = O.ddim_overlapping(sd, cfg, xT, xc_cpu, None, corners, 16, 6)
+    xs, _ = d.sample_image(d.wavelet_dec(2 * img.cuda() - 1), xT.cuda(), x_other=None, last=False, patch_locs=corners, patch_size=16,
+                           use_other=False)
+    assert rel_linf(xs[-1].cpu(), xs_o[-1]) <= TOL[dtype]
+
+
 def test_checkpoint_formats(tmp_path):
     """--resume with the reference's checkpoint dict (utils/logging.py:15-18, ddm_wavelet.py:180-190, :282-292): DDP-prefixed or
     plain state_dict keys, the EMA shadow dict, strict key checking."""

@@ -41,6 +41,26 @@ def test_param_table_matches_reference_state_dict_layout(cfg):
     assert int(_lib.lib().wdm_unet_workspace_bytes(net._u, 4)) > 0
 
 
+@pytest.mark.parametrize("kind", P.VARIANTS)
+def test_optional_branch_param_tables(golden, kind):
+    """The optional config branches change conv_in / conv_out widths and (wavelet_in_unet) add two frozen Haar weights."""
+    import wavedm_amd
+    cfg, _ = P.variant_config(kind)
+    net = wavedm_amd.DiffusionUNet(cfg, dtype="f32")
+    sd = net.state_dict()
+    frozen = [k for k in sd if k.startswith("wavelet_")]
+    want = P.unet_param_shapes(cfg)
+    assert {k for k in sd if k not in frozen} == set(want.keys())
+    assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    assert tuple(sd["conv_in.weight"].shape)[1] == P.unet_in_channels(cfg) == {"no_other": 51, "window": 24, "wavelet_in_unet": 96}[kind]
+    v = golden("variants.npz")
+    assert frozen == (["wavelet_dec.conv.weight", "wavelet_rec.conv.weight"] if kind == "wavelet_in_unet" else [])
+    for k in frozen:                                            # same values as the reference un-pickles
+        assert np.array_equal(sd[k].numpy(), v[kind + ":" + k]) and not dict(net.named_parameters())[k].requires_grad
+    full = dict(P.procedural_state_dict(cfg, seed=61), **{k: torch.from_numpy(v[kind + ":" + k]) for k in frozen})
+    net.load_state_dict(full, strict=True)
+
+
 def test_no_cpu_fallback():
     import wavedm_amd
     with pytest.raises(TypeError):
@@ -59,7 +79,7 @@ def test_bad_arguments_return_errors_not_crashes():
     cfg.ch_mult[0], cfg.ch_mult[1], cfg.resamp_with_conv, cfg.dtype = 1, 2, 1, 1
     u = C.c_void_p()
     assert L.wdm_unet_create(None, C.byref(cfg), C.byref(u)) == -1                           # ch % 32 != 0
-    assert b"multiples of 32" in L.wdm_last_error()
+    assert b"multiple of 32" in L.wdm_last_error()
     cfg.ch, cfg.resolution = 32, 12
     assert L.wdm_unet_create(None, C.byref(cfg), C.byref(u)) == -1                           # 12/2 = 6 not a multiple of 8
     cfg.resolution = 16

@@ -1,6 +1,7 @@
 """CPU: the oracle restatement reproduces the committed golden vectors, which were produced by
 running the reference itself (tests/golden/make_golden.py).  No GPU, no /root/reference."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import rel_linf
@@ -121,6 +122,20 @@ def test_stitched_restore(golden):
     assert int(s["n_corners"]) == len(O.grid_corners(30, 45, 16, 4))
     assert out.shape == (1, 3, 120, 180) and float(out.min()) >= 0 and float(out.max()) <= 1
     assert rel_linf(out, s["out"]) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", P.VARIANTS)
+def test_optional_unet_branches(golden, kind):
+    """use_other_channels False, data.use_window, data.wavelet_in_unet (unet.py:212, :347-350, :387-391)."""
+    v = golden("variants.npz")
+    cfg, shape = P.variant_config(kind)
+    sd = P.procedural_state_dict(cfg, seed=61)
+    y = O.unet_forward(sd, cfg, seeded(shape, 700), torch.tensor([400.0, 30.0]))
+    assert tuple(y.shape) == v[kind].shape == (2, 3) + tuple(shape[2:])
+    assert rel_linf(y, v[kind]) <= 1e-5
+    if kind == "wavelet_in_unet":                  # the frozen (de)conv weights the reference keeps in its state_dict
+        w = O.haar_filters().repeat(3, 1, 1).unsqueeze(1)
+        assert np.array_equal(w.numpy(), v[kind + ":wavelet_dec.conv.weight"]) and np.array_equal(w.numpy(), v[kind + ":wavelet_rec.conv.weight"])
 
 
 def test_param_layout_full():

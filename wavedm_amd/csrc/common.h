@@ -133,8 +133,10 @@ int k_timestep_embedding(const float* t, int n_t, int dim, float* emb, hipStream
 int k_linear(const float* in, int n, int k, const float* W, const float* b, int o, float* out, int act, hipStream_t s);
 // weight packing: OIHW f32 -> [tap][rows_pad][cin] dtype, written at row offset `row_off` of a `rows_total` matrix
 // rows [row_off + cout, rows_total) are zero-filled when zero_tail != 0
+// cin_dst > cin: destination rows are cin_dst long, the extra columns zero (0 = cin)
 int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail,
-                int dtype, hipStream_t s);
+                int dtype, hipStream_t s, int cin_dst = 0);
+int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
 
 // ---- live kernel timing (prof.hip): HIP events on the launch stream around every conv launch ------

@@ -512,24 +512,43 @@ int k_linear(const float* in, int n, int k, const float* W, const float* b, int 
 // weight packing: OIHW f32 -> [tap][rows_total][cin] in the model dtype
 // =================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int cout, int cin, int kk, T* __restrict__ dst, int rows_total, int row_off,
-                                                        int rows_span) {
-    // rows [row_off, row_off + cout) get the weights, rows [row_off + cout, row_off + rows_span) are zero padding
-    const long long total = (long long)rows_span * cin * kk;
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int cout, int cin, int cin_dst, int kk, T* __restrict__ dst, int rows_total,
+                                                        int row_off, int rows_span) {
+    // rows [row_off, row_off + cout) get the weights, rows [row_off + cout, row_off + rows_span) are zero padding; so are the
+    // columns [cin, cin_dst) (conv_in of models whose input channel count is not a multiple of the K slab)
+    const long long total = (long long)rows_span * cin_dst * kk;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        const int ci = (int)(id % cin);
-        const int o = (int)((id / cin) % rows_span);
-        const int tap = (int)(id / ((long long)cin * rows_span));
-        const float v = (o < cout) ? w[((long long)o * cin + ci) * kk + tap] : 0.f;
-        TI<T>::st(dst, ((long long)tap * rows_total + row_off + o) * cin + ci, v);
+        const int ci = (int)(id % cin_dst);
+        const int o = (int)((id / cin_dst) % rows_span);
+        const int tap = (int)(id / ((long long)cin_dst * rows_span));
+        const float v = (o < cout && ci < cin) ? w[((long long)o * cin + ci) * kk + tap] : 0.f;
+        TI<T>::st(dst, ((long long)tap * rows_total + row_off + o) * cin_dst + ci, v);
     }
 }
-int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail, int dtype, hipStream_t s) {
+int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail, int dtype, hipStream_t s, int cin_dst) {
+    if (cin_dst <= 0) cin_dst = cin;
     const int rows_span = zero_tail ? rows_total - row_off : cout;
-    const long long total = (long long)rows_span * cin * k * k;
+    const long long total = (long long)rows_span * cin_dst * k * k;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, k * k, (__bf16*)dst, rows_total, row_off, rows_span);
-    else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, k * k, (float*)dst, rows_total, row_off, rows_span);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, cin_dst, k * k, (__bf16*)dst, rows_total, row_off, rows_span);
+    else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, cin_dst, k * k, (float*)dst, rows_total, row_off, rows_span);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+// y[row][0..Cp) = x[row][0..C) followed by zeros (dense rows)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_channels2_kernel(const T* __restrict__ x, int C, int Cp, T* __restrict__ y, long long total) {
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id % Cp);
+        const long long r = id / Cp;
+        TI<T>::st(y, id, c < C ? TI<T>::ld(x, r * C + c) : 0.f);
+    }
+}
+int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s) {
+    const long long total = rows * Cp;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    if (dtype == WDM_BF16) hipLaunchKernelGGL(pad_channels2_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, C, Cp, (__bf16*)y, total);
+    else hipLaunchKernelGGL(pad_channels2_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, C, Cp, (float*)y, total);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }

@@ -560,6 +560,8 @@ extern "C" {
 int wdm_trainer_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_trainer** out) {
     if (!cfg || !out) WDM_FAIL(WDM_EINVAL, "wdm_trainer_create: null argument");
     if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32) WDM_FAIL(WDM_EINVAL, "wdm_trainer_create: bad dtype");
+    if (cfg->ch % 32 || cfg->in_channels % 32 || cfg->in_channels < 32)
+        WDM_FAIL(WDM_EINVAL, "wdm_trainer_create: ch and in_channels must be multiples of 32 (the training step covers the [x_cond | x_t | x_other] input of raindrop_wavelet.yml)");
     wdm_trainer* t = new wdm_trainer();
     t->cfg = *cfg;
     t->build();

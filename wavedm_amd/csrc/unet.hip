@@ -26,6 +26,7 @@ struct ParamSlot {
     int rows_total = 0;   // PK_CONV: rows of the destination matrix (fused qk: 2C)
     int row_off = 0;      // PK_CONV: first destination row;  PK_F32: element offset inside the destination vector
     bool zero_tail = true;   // PK_CONV: this slot also zero-fills the padding rows behind it
+    int cin_dst = 0;         // PK_CONV: row length of the destination when it is padded beyond shape[1] (conv_in), else 0
     bool loaded = false;
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 };
@@ -66,12 +67,15 @@ struct wdm_unet {
         index[name] = (int)params.size();
         params.push_back(p);
     }
-    ConvD add_conv(const std::string& name, int cin, int cout, int k) {
+    // cin_pad > cin: the kernels' K dimension is padded with zero columns (conv_in of a model whose input width is not a multiple of 32)
+    ConvD add_conv(const std::string& name, int cin, int cout, int k, int cin_pad = 0) {
         ConvD d{};
-        d.cin = cin; d.cout = cout; d.k = k; d.rows_pad = conv_rows_pad(cout);
-        d.w_off = take(conv_packed_bytes(cin, cout, k, cfg.dtype));
+        if (cin_pad <= 0) cin_pad = cin;
+        d.cin = cin_pad; d.cout = cout; d.k = k; d.rows_pad = conv_rows_pad(cout);
+        d.w_off = take(conv_packed_bytes(cin_pad, cout, k, cfg.dtype));
         d.b_off = take((size_t)cout * 4);
         add_param(name + ".weight", {cout, cin, k, k}, PK_CONV, d.w_off, d.rows_pad, 0);
+        params.back().cin_dst = cin_pad != cin ? cin_pad : 0;
         add_param(name + ".bias", {cout}, PK_F32, d.b_off, 0, 0);
         return d;
     }
@@ -148,7 +152,7 @@ int wdm_unet::build() {
     d1w = take((size_t)temb_ch * temb_ch * 4); d1b = take((size_t)temb_ch * 4);
     add_param("temb.dense.1.weight", {temb_ch, temb_ch}, PK_F32, d1w, 0, 0);
     add_param("temb.dense.1.bias", {temb_ch}, PK_F32, d1b, 0, 0);
-    conv_in = add_conv("conv_in", cfg.in_channels, ch, 3);
+    conv_in = add_conv("conv_in", cfg.in_channels, ch, 3, (int)align_up((size_t)cfg.in_channels, 32));
 
     int res = cfg.resolution;
     int block_in = ch;
@@ -220,9 +224,17 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
 
     Tens x;
     x.p = (void*)x96; x.C = cfg.in_channels; x.H = R; x.W = R; x.xs = cfg.in_channels;
+    void* xpad = nullptr;
+    if (conv_in.cin != cfg.in_channels) {      // input width not a multiple of the K slab: zero-padded copy (the weights carry zero columns)
+        xpad = c.ar->alloc((size_t)c.B * R * R * conv_in.cin * dsize(c.dtype));
+        if (!xpad) WDM_FAIL(WDM_ENOMEM, "workspace too small (padded input)");
+        if (!c.dry) WDM_TRY(k_pad_channels(x96, cfg.in_channels, conv_in.cin, xpad, (long long)c.B * R * R, c.dtype, c.s));
+        x.p = xpad; x.C = conv_in.cin; x.xs = conv_in.cin;
+    }
     std::vector<Tens> hs;
     Tens h;
     WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr, true));
+    if (xpad) c.ar->free(xpad);
     hs.push_back(h);
     for (int l = 0; l < nres; ++l) {
         for (int b = 0; b < nrb; ++b) {
@@ -313,9 +325,9 @@ int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out) {
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad level count");
     if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
     if (!cfg->resamp_with_conv) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resamp_with_conv=False is not supported");
-    if (cfg->ch % 32 || cfg->in_channels % 32) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: ch and in_channels must be multiples of 32");
+    if (cfg->ch % 32 || cfg->in_channels < 1) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: ch must be a multiple of 32");
     if (cfg->resolution % (8 << (cfg->n_levels - 1))) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resolution %d too small for %d levels (coarsest level must be a multiple of 8)", cfg->resolution, cfg->n_levels);
-    if (cfg->out_ch > 16) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: out_ch > 16 unsupported");
+    if (cfg->out_ch < 1) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: out_ch must be positive");
     wdm_unet* u = new wdm_unet();
     u->h = h;
     u->cfg = *cfg;
@@ -354,7 +366,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     hipStream_t s = (hipStream_t)stream;
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
-        WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s));
+        WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
     } else {
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
     }

@@ -187,8 +187,8 @@ class DenoisingDiffusion_Wavelet(object):
             raise NotImplementedError("only eta = 0 (DDIM) is used by the reference (ddm_wavelet.py:303)")
         if use_global:
             raise NotImplementedError("use_global=True is outside the accelerated path")
-        if not (use_other and x_other is not None):
-            raise NotImplementedError("use_other=False changes the UNet input width; raindrop_wavelet.yml sets it True")
+        if not use_other:
+            x_other = None                                                      # ddm_wavelet.py:471-473: the UNet sees [x_cond | x_t] only
         if not self.config.data.begin_from_noise:                              # ddm_wavelet.py:445-447
             a = (1 - b).cumprod(dim=0)[self.num_timesteps - 1]
             x = x_cond[:, :x.shape[1]] * a.sqrt() + x * (1.0 - a).sqrt()

@@ -57,6 +57,28 @@ def reduced_config():
     return raindrop_wavelet_config(image_size=16, ch=32, ch_mult=(1, 2), attn_resolutions=(8,))
 
 
+def variant_config(kind):
+    """Reduced configs exercising the optional branches of `models/unet.py` + the NCHW input shape each takes:
+    "no_other" (model.use_other_channels False: 48 + 3 input channels), "window" (data.use_window: 6 image channels at 32x32 ->
+    2 x 12 window channels at 16x16, 12 -> 3 back), "wavelet_in_unet" (DWT/IDWT inside the model: 6 channels at 64x64 -> 96 at 16x16)."""
+    c = reduced_config()
+    if kind == "no_other":
+        c.model.use_other_channels = False
+        return c, (2, 51, 16, 16)
+    if kind == "window":
+        c.data.use_window, c.data.window_size = True, 2
+        c.model.use_other_channels, c.model.in_channels, c.model.pred_channels, c.model.out_ch = False, 12, 12, 12
+        return c, (2, 6, 32, 32)
+    if kind == "wavelet_in_unet":
+        c.data.wavelet_in_unet = True
+        c.model.use_other_channels, c.model.in_channels, c.model.pred_channels, c.model.out_ch = False, 48, 48, 48
+        return c, (2, 6, 64, 64)
+    raise ValueError(kind)
+
+
+VARIANTS = ("no_other", "window", "wavelet_in_unet")
+
+
 def unet_in_channels(config) -> int:
     m = config.model
     if m.use_other_channels:

@@ -80,11 +80,12 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
     """
     x = _lib.require_cuda_f32(x, "x")
     x_cond = _lib.require_cuda_f32(x_cond, "x_cond")
-    x_other = _lib.require_cuda_f32(x_other, "x_other")
+    if x_other is not None:
+        x_other = _lib.require_cuda_f32(x_other, "x_other")
     dev = x.device
     L, h = _lib.lib(), _lib.handle(dev.index or 0)
     nimg, pc, H, W = x.shape
-    ncond, nother = x_cond.shape[1], x_other.shape[1]
+    ncond, nother = x_cond.shape[1], (x_other.shape[1] if x_other is not None else 0)      # x_other None: model.use_other_channels False
     cin = unet.in_channels
     assert ncond + pc + nother == cin, f"channel split {ncond}+{pc}+{nother} != UNet in_channels {cin}"
     with torch.cuda.device(dev):
@@ -119,7 +120,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         x96 = torch.empty(max(n, 1), p, p, cin, device=dev, dtype=unet._torch_dtype)
         if n:
             _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
-            _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
+            if nother:
+                _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
         eps = torch.empty(max(n, 1), pc, p, p, device=dev, dtype=torch.float32)
         acc_cnt = torch.empty(2 * x.numel(), device=dev, dtype=torch.float32) if sharded else None
 

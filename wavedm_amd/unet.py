@@ -60,10 +60,13 @@ class DiffusionUNet(nn.Module):
     def __init__(self, config, dtype=None):
         super().__init__()
         d = config.data
-        if getattr(d, "use_window", False) or getattr(d, "wavelet_in_unet", False) or getattr(d, "global_attn", False):
-            raise NotImplementedError("use_window / wavelet_in_unet / global_attn are off in raindrop_wavelet.yml and "
-                                      "outside the accelerated path (SURVEY.md §8f-4)")
+        if getattr(d, "global_attn", False):
+            raise NotImplementedError("data.global_attn (DiffusionUNet_Global, unet.py:397-636) is not built (SURVEY.md §8f-4)")
         self.config = config
+        # optional input / output re-arrangements around the same network (unet.py:309-350, :387-391), off in raindrop_wavelet.yml
+        self.use_window = bool(getattr(d, "use_window", False))
+        self.window_size = int(getattr(d, "window_size", 2))
+        self.use_wavelet_in_unet = bool(getattr(d, "wavelet_in_unet", False))
         self.resolution = int(d.image_size)
         self.in_channels = unet_in_channels(config)
         self.out_ch = int(config.model.out_ch)
@@ -76,6 +79,10 @@ class DiffusionUNet(nn.Module):
         u = C.c_void_p()
         _lib.check(L.wdm_unet_create(None, C.byref(self._cfg), C.byref(u)))
         self._u = u
+        if self.use_wavelet_in_unet:                         # registered first, like unet.py:204-206 (frozen, state_dict keys only)
+            from .wavelet import WaveletTransform
+            self.wavelet_dec = WaveletTransform(scale=2, dec=True)
+            self.wavelet_rec = WaveletTransform(scale=2, dec=False)
         self._names = []
         name, ndim, shape = C.c_char_p(), C.c_int(), (C.c_int64 * 4)()
         for i in range(L.wdm_unet_num_params(u)):
@@ -184,8 +191,32 @@ class DiffusionUNet(nn.Module):
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         return eps_out
 
+    # ---- unet.py:309-344 ---------------------------------------------------------------------------
+    @staticmethod
+    def to_win(x, p):
+        B, Cc, H, W = x.shape
+        return x.view(B, Cc, p, H // p, p, W // p).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, -1, H // p, W // p)
+
+    @staticmethod
+    def win_back(x, p):
+        B, Cc, H, W = x.shape
+        return x.view(B, Cc // (p * p), p, p, H, W).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, Cc // (p * p), H * p, W * p)
+
     def forward(self, x, t):
         x = _lib.require_cuda_f32(x, "DiffusionUNet input")
+        if self.use_window:                                  # convert_image_to_patches (:323-331)
+            p = self.window_size
+            x = torch.cat([self.to_win(x[:, :3].contiguous(), p), self.to_win(x[:, 3:].contiguous(), p)], dim=1)
+        if self.use_wavelet_in_unet:                         # all_wavlet_dec (:338-344)
+            x = torch.cat([self.wavelet_dec(x[:, :3].contiguous()), self.wavelet_dec(x[:, 3:].contiguous())], dim=1)
+        h = self._core_forward(x.contiguous(), t)
+        if self.use_window:
+            h = self.win_back(h, self.window_size)           # convert_patches_to_image (:333-336)
+        if self.use_wavelet_in_unet:
+            h = self.wavelet_rec(h.contiguous())
+        return h
+
+    def _core_forward(self, x, t):
         B, Cc, H, W = x.shape
         assert H == W == self.resolution, "input resolution != config.data.image_size (unet.py:351)"
         assert Cc == self.in_channels and t.dim() == 1
