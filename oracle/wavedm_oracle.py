@@ -462,6 +462,37 @@ def synthetic_raindrop_dir(root, seed=303, sizes=((1000, 640), (300, 500), (720,
 # SURVEY.md §8(f)-3  training step   (reference: models/ddm_wavelet.py:108-124 loss, :200-272 step, :34-60 EMA,
 # utils/optimize.py:5-8 Adam(lr, betas=(0.9,0.999), eps, weight_decay, amsgrad=False))
 # ------------------------------------------------------------------------------------------------
+def make_grid(tensor, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid (torchvision==0.9.0 per the reference's requirements.txt:9; the package is absent from this image,
+    so this restates its published algorithm) as called at ddm_wavelet.py:409: normalize=False, scale_each=False.
+    xmaps = min(nrow, N), ymaps = ceil(N / xmaps); cell = (H + padding, W + padding); the canvas is filled with pad_value and image k
+    is narrowed into row k // xmaps, column k % xmaps at offset `padding`."""
+    import math
+    if tensor.dim() == 2:
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 3:
+        if tensor.size(0) == 1:
+            tensor = torch.cat((tensor, tensor, tensor), 0)
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 4 and tensor.size(1) == 1:
+        tensor = torch.cat((tensor, tensor, tensor), 1)
+    if tensor.size(0) == 1:
+        return tensor.squeeze(0)
+    nmaps = tensor.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(math.ceil(float(nmaps) / xmaps))
+    height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+    grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for yy in range(ymaps):
+        for xx in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, yy * height + padding, height - padding).narrow(2, xx * width + padding, width - padding).copy_(tensor[k])
+            k += 1
+    return grid
+
+
 def noise_estimation_loss(sd, config, x0, t, e, betas):
     """ddm_wavelet.py:108-124 for the raindrop_wavelet.yml branch (use_other_channels, inp_channels = 48, pred_channels = 3).
     x0: (B, 96, R, R) = [x_cond 48 | gt LL 3 | other 45]; t: (B,) long; e: (B,3,R,R).  -> (simple_loss, output, x0_pred, mse_loss)"""

@@ -252,3 +252,52 @@ def test_train_loop_on_synthetic_dataset(tmp_path):
     d.sync_from_trainer(ema=True)
     x96 = seeded((1, 96, 16, 16), 40).to(dev())
     assert bool(torch.isfinite(d.model(x96, torch.tensor([500.0]))).all())
+
+
+def test_train_loop_validation_sheet(tmp_path):
+    """The training loop's periodic validation restore (ddm_wavelet.py:273-278, :340-411): at step 10 (single process) rank 0 restores
+    the first two validation images and writes one 4-column sheet [input | LL from the sampler + gt bands | output | gt]."""
+    import os
+    import random
+    from types import SimpleNamespace
+    import numpy as np
+    from PIL import Image
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    from wavedm_amd.datasets import RainDrop
+    O.synthetic_raindrop_dir(str(tmp_path), seed=303, sizes=((200, 140), (200, 140), (200, 140)))
+    import shutil
+    shutil.copytree(tmp_path / "raindrop" / "raindrop_test", tmp_path / "raindrop" / "train")
+    cfg = P.reduced_config()
+    cfg.device = dev()
+    cfg.data.data_dir, cfg.data.patch_size = str(tmp_path), 64
+    cfg.training = SimpleNamespace(patch_n=2, batch_size=1, n_epochs=8, snapshot_freq=1000, validation_freq=1000)
+    cfg.optim = SimpleNamespace(lr=1e-4, eps=1e-8, weight_decay=0.0)
+    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder=str(tmp_path / "img"), test_set="raindrop", grid_r=4,
+                           world_size=1, rank=0)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="bf16")
+    d.model.load_state_dict(P.procedural_state_dict(cfg), strict=True)
+    random.seed(1)
+    torch.manual_seed(1)
+    d.train(RainDrop(args, cfg), max_steps=10)
+    assert d.step == 10
+    folder = tmp_path / "img" / cfg.data.dataset / "raindrop"
+    sheets = sorted(os.listdir(folder))
+    assert len(sheets) == 1 and sheets[0].endswith("_output_epoch3.png")          # 3 training items per epoch: step 10 is in epoch 3
+    sheet = np.asarray(Image.open(folder / sheets[0]))
+    _, val_loader = RainDrop(args, cfg).get_loaders(parse_patches=False, validation="raindrop")
+    items = list(val_loader)
+    H, W = items[0][0].shape[-2:]
+    assert sheet.shape == (2 * (H + 2) + 2, 4 * (W + 2) + 2, 3)
+    u8 = lambda t: (t[0].mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy()
+    seen = []
+    for row in range(2):
+        y0 = row * (H + 2) + 2
+        col = lambda c: sheet[y0:y0 + H, c * (W + 2) + 2:c * (W + 2) + 2 + W]
+        match = [k for k, (x, y, total) in enumerate(items) if np.array_equal(col(0), u8(x[:, :3]))]   # column 0: a degraded input ...
+        assert len(match) == 1 and match[0] not in seen
+        seen.append(match[0])
+        assert np.array_equal(col(3), u8(items[match[0]][0][:, 3:]))                                     # ... column 3: its ground truth
+        assert col(1).std() > 0 and col(2).std() > 0
+    assert sheets[0].startswith(str(items[seen[-1]][1]))                                                 # named after the last item restored
+    assert not sheet[:2].any() and not sheet[:, :2].any()                                              # frame = pad_value 0

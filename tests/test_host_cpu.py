@@ -163,3 +163,14 @@ def test_trainer_param_table_on_host():
         assert spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:]))
         assert spans[-1][0] + spans[-1][1] == int(L.wdm_trainer_num_floats(t)) == sum(int(np.prod(v)) for v in want.values())
         L.wdm_trainer_destroy(t)
+
+
+def test_make_grid_matches_torchvision_layout():
+    """imageio.make_grid against the oracle's restatement of torchvision.utils.make_grid (validation sheet, ddm_wavelet.py:407-410)."""
+    from wavedm_amd.imageio import make_grid
+    g = torch.Generator().manual_seed(3)
+    for (n, c, h, w, nrow, pad) in [(8, 3, 12, 20, 4, 2), (5, 3, 7, 9, 4, 2), (1, 3, 6, 6, 4, 2), (3, 1, 5, 4, 8, 1), (4, 3, 8, 8, 4, 0)]:
+        t = torch.rand(n, c, h, w, generator=g)
+        a, b = make_grid(t, nrow=nrow, padding=pad), O.make_grid(t, nrow=nrow, padding=pad)
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert tuple(make_grid(torch.rand(8, 3, 12, 20), nrow=4).shape) == (3, 2 * 14 + 2, 4 * 22 + 2)

@@ -146,8 +146,9 @@ class DenoisingDiffusion_Wavelet(object):
         self.model.pack_weights(force=True)
 
     def train(self, DATASET, max_steps=None):
-        """ddm_wavelet.py:200-292 without the periodic validation restore: epochs over DATASET.get_loaders()[0], a checkpoint in the
-        reference's format every `training.snapshot_freq` steps.  `max_steps` bounds the run (tests, benchmarks)."""
+        """ddm_wavelet.py:200-292: epochs over DATASET.get_loaders()[0]; on rank 0 the validation sheet (`restore`, :273-278) every
+        `training.validation_freq` steps (every 10 when single-process, as the reference) and a checkpoint in the reference's format
+        every `training.snapshot_freq` steps.  `max_steps` bounds the run (tests, benchmarks)."""
         import torch.distributed as dist
         train_loader, _ = DATASET.get_loaders()
         tr = getattr(self, "trainer", None) or self.make_trainer()
@@ -158,6 +159,12 @@ class DenoisingDiffusion_Wavelet(object):
                 loss = self.train_step(x)
                 if self.step % 10 == 0 and rank0:
                     print(f"step: {self.step}, loss: {float(loss)}, loss mean: {float(loss) / npix}")
+                world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+                vfreq = int(getattr(self.config.training, "validation_freq", 0) or 0) if world > 1 else 10
+                if rank0 and vfreq > 0 and self.step % vfreq == 0:                                    # :273-278
+                    self.sync_from_trainer()
+                    _, val_loader = DATASET.get_loaders(parse_patches=False, validation=self.args.test_set)
+                    self.restore(val_loader, validation=self.args.test_set, r=self.args.grid_r, epoch=epoch)
                 if rank0 and (self.step % self.config.training.snapshot_freq == 0 or self.step == 1):
                     path = os.path.join(self.config.data.data_dir, "ckpts", f"{self.config.data.dataset}_epoch{epoch + 1}_ddpm.pth.tar")
                     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -216,6 +223,46 @@ class DenoisingDiffusion_Wavelet(object):
         x = torch.randn((x_cond.shape[0], self.config.model.pred_channels, x_cond.shape[2], x_cond.shape[3]), device=self.device)
         return self.sample_image(x_cond, x, x_other=x_other, patch_locs=corners, last=last, patch_size=p_size,
                                  total=total, use_global=use_global, use_other=use_other)
+
+    def restore(self, val_loader, validation="snow", r=None, epoch=0):
+        """ddm_wavelet.py:340-411, the training loop's validation sheet: the first two items of `val_loader` are restored and
+        [input | x0_preds[-5] LL + ground-truth bands | output | ground truth] of each go into one 4-column PNG
+        `<image_folder>/<dataset>/<validation>/<y>_output_epoch<epoch>.png`.  Returns that path."""
+        cfg = self.config
+        if not (cfg.data.wavelet and not cfg.data.wavelet_in_unet and cfg.model.use_other_channels):
+            raise NotImplementedError("DenoisingDiffusion_Wavelet.restore: only the raindrop_wavelet.yml branch is accelerated")
+        from . import imageio
+        image_folder = os.path.join(self.args.image_folder, cfg.data.dataset, validation)
+        pc, ob = cfg.model.pred_channels, cfg.model.other_channels_begin
+        tiles, y = [], None
+        with torch.no_grad():
+            for i, (x, y, total) in enumerate(val_loader):
+                print(f"starting processing from image {y}")
+                x = x.flatten(start_dim=0, end_dim=1) if x.ndim == 5 else x
+                x = x.to(self.device).float().contiguous()
+                x_all = data_transform(x)
+                inp, gt = x[:, :3].contiguous(), x[:, 3:].contiguous()
+                x_cond = self.wavelet_dec(x_all[:, :3].contiguous())
+                x_gt = self.wavelet_dec(x_all[:, 3:].contiguous())
+                hf_wav = self.wavelet_dec(data_transform(self.generator(inp)).contiguous())
+                _, x0_preds = self.diffusive_restoration(x_cond, x_other=hf_wav[:, ob:].contiguous(), r=r, last=False,
+                                                         use_global=False, use_other=True)
+                pred = x0_preds[-5]
+                rec = lambda lo, hi: inverse_data_transform(self.wavelet_rec(torch.cat([lo[:, :pc], hi[:, pc:]], dim=1).contiguous()))
+                x_output, hrgt = rec(pred, hf_wav), rec(pred, x_gt)
+                H, W = x_output.shape[-2:]
+                print("psnr", imageio.psnr_from_sums(imageio.sqdiff(gt, x_output), H, W)[0][0])
+                tiles += [inp, hrgt, x_output, gt]            # IDWT(DWT(x)) == x: the "cond" tile is the input
+                if i == 1:
+                    break
+        if not tiles:
+            return None
+        grid = imageio.make_grid(torch.cat(tiles, dim=0), nrow=4)
+        path = os.path.join(image_folder, f"{y}_output_epoch{epoch}.png")
+        os.makedirs(image_folder, exist_ok=True)
+        from PIL import Image
+        Image.fromarray(imageio.to_u8_hwc(grid)[0].cpu().numpy()).save(path)
+        return path
 
     # ---- batched independent crops (BASELINE.json configs 0-3) --------------------------------------------
     def restore_batch(self, rainy01, x_T, hfrm_out01=None, keep=-5, early_stop=False):

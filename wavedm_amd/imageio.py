@@ -27,6 +27,27 @@ def to_u8_hwc(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def make_grid(tensor: torch.Tensor, nrow: int = 8, padding: int = 2, pad_value: float = 0.0) -> torch.Tensor:
+    """torchvision.utils.make_grid's layout (torchvision is not a dependency here): (N,C,H,W) -> (C, rows*(H+pad)+pad, cols*(W+pad)+pad)
+    with cols = min(nrow, N), image k at row k // cols, column k % cols; one image is returned unframed; 1-channel input is repeated
+    to 3.  Used by the training loop's validation sheet (ddm_wavelet.py:407-410).  Works on any device."""
+    if tensor.dim() == 3:
+        tensor = tensor[None]
+    if tensor.shape[1] == 1:
+        tensor = tensor.expand(-1, 3, -1, -1)
+    N, Cc, H, W = tensor.shape
+    if N == 1:
+        return tensor[0]
+    cols = min(int(nrow), N)
+    rows = (N + cols - 1) // cols
+    h, w = H + padding, W + padding
+    grid = tensor.new_full((Cc, h * rows + padding, w * cols + padding), float(pad_value))
+    for k in range(N):
+        r, c = divmod(k, cols)
+        grid[:, r * h + padding:r * h + padding + H, c * w + padding:c * w + padding + W] = tensor[k]
+    return grid
+
+
 def sqdiff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Per-image [sum (clamp a - clamp b)^2 over RGB, sum (Y(a)-Y(b))^2] in fp64 on the device: (B,2)."""
     a, b = _lib.require_cuda_f32(a, "metrics input"), _lib.require_cuda_f32(b, "metrics input")
