@@ -16,21 +16,35 @@ namespace wdm {
 static inline int nblk(long long n, int bs) { long long g = (n + bs - 1) / bs; return (int)(g > 16384 ? 16384 : g); }
 
 // dst[b][c][k] (row length kp, k = oy*Wo + ox; image stride dst_img elements) = src[b][stride*oy + off_y][stride*ox + off_x][c]
-// (0 outside the map / past Ho*Wo)
+// (0 outside the map / past Ho*Wo); rows C <= c < Crows are written as zeros.  A 64-channel x 64-position tile per workgroup goes
+// through LDS, so the reads run along the channels of a pixel and the writes along the positions of a channel: both coalesced.
 template <typename T>
-__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int C, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
-                                                       T* __restrict__ dst, long long dst_img, int kp, long long total) {
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(id % kp);
-        const int c = (int)((id / kp) % C);
-        const long long b = id / ((long long)kp * C);
-        float v = 0.f;
-        if (k < Ho * Wo) {
-            const int oy = k / Wo, ox = k - oy * Wo;
-            const int y = stride * oy + off_y, x = stride * ox + off_x;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = TI<T>::ld(src, ((b * H + y) * W + x) * xs + c);
+__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int C, int Crows, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
+                                                       T* __restrict__ dst, long long dst_img, int kp) {
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const long long b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (c0 < C) {
+        const int c = c0 + tx;
+        for (int j = ty; j < 64; j += 4) {
+            const int k = k0 + j;
+            float v = 0.f;
+            if (c < C && k < Ho * Wo) {
+                const int oy = k / Wo, ox = k - oy * Wo;
+                const int y = stride * oy + off_y, x = stride * ox + off_x;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = TI<T>::ld(src, ((b * H + y) * W + x) * xs + c);
+            }
+            tile[j][tx] = v;
         }
-        TI<T>::st(dst, b * dst_img + (long long)c * kp + k, v);
+    }
+    __syncthreads();
+    const int k = k0 + tx;
+    if (k >= kp) return;
+    for (int j = ty; j < 64; j += 4) {
+        const int c = c0 + j;
+        if (c >= Crows) break;
+        TI<T>::st(dst, b * dst_img + (long long)c * kp + k, c0 < C ? tile[tx][j] : 0.f);
     }
 }
 // grad[co][ci][tap] (OIHW f32) (+)= sum_b partial[tap][b][co][ci]   (rows_g rows per image in the partial buffer)
@@ -111,17 +125,28 @@ __global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ dy,
         TI<T>::st(dx, id, s);
     }
 }
-// dgrad weights: dst[tap'][row = ci][k = co] = w[co][ci][taps-1-tap'] (transposed, taps mirrored), k zero-padded to kpad, rows to rows_total
-template <typename T>
-__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, int cout, int cin, int kk, T* __restrict__ dst, int rows_total, int kpad) {
-    const long long total = (long long)kk * rows_total * kpad;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(id % kpad);
-        const int ci = (int)((id / kpad) % rows_total);
-        const int tp = (int)(id / ((long long)kpad * rows_total));
-        const float v = (co < cout && ci < cin) ? w[((long long)co * cin + ci) * kk + (kk - 1 - tp)] : 0.f;
-        TI<T>::st(dst, id, v);
+// dgrad weights: dst[tap'][row = ci][k = co] = w[co][ci][taps-1-tap'] (transposed, taps mirrored), k zero-padded to kpad, rows to rows_total.
+// One workgroup per 32 (co) x 32 (ci) block: the OIHW rows are read contiguously (32 ci x taps floats per co) into LDS, each tap is
+// written as 32-element runs along co.
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total, int kpad) {
+    constexpr int ROW = 32 * KK;
+    __shared__ float sm[32][ROW + 1];
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int nci = min(32, cin - ci0);             // may be <= 0 for the zero-padded rows
+    for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+        const int co = co0 + r;
+        for (int e = threadIdx.x & 31; e < ROW; e += 32)
+            sm[r][e] = (co < cout && e < nci * KK) ? w[((long long)co * cin + ci0) * KK + e] : 0.f;
     }
+    __syncthreads();
+    const int co = co0 + (threadIdx.x & 31);
+    if (co >= kpad) return;
+    for (int tp = 0; tp < KK; ++tp)
+        for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+            const int ci = ci0 + r;
+            if (ci < rows_total) TI<T>::st(dst, ((long long)tp * rows_total + ci) * kpad + co, sm[threadIdx.x & 31][r * KK + (KK - 1 - tp)]);
+        }
 }
 // y = x with channels zero-padded from C to Cp (dense)
 template <typename T>
@@ -143,36 +168,47 @@ __global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x
                                                          const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean_rstd, int silu, T* __restrict__ dx0, int acc0, T* __restrict__ dx1, int acc1,
                                                          float* __restrict__ dgam_part, float* __restrict__ dbet_part) {
-    __shared__ float wsum[2][4];
+    __shared__ float red[2][256];
     __shared__ float msum[2];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int gw = C / 32, cg0 = g * gw, C1 = C - C0;
     const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
-    // phase 1: wave w owns channels w, w+4, ... of the group: per-channel sums over the image's pixels by shuffles only
-    float Sa = 0.f, Sb = 0.f;                       // lane 0 of each wave
-    for (int ci = wv; ci < gw; ci += 4) {
-        const int c = cg0 + ci;
-        const float gm = gamma[c], bt = beta[c];
+    // phase 1: thread = (pixel row pr, channel ci of the group), ci fastest, so a wave reads runs of gw contiguous channels; every thread
+    // sums its channel over the pixels pr, pr + npr, ...; the npr partial sums of a channel are then added in order
+    const int npr = 256 / gw;                         // gw <= 256, checked by the host
+    {
+        const int ci = tid % gw, pr = tid / gw;
         float sg = 0.f, sb = 0.f;
-        for (int p = lane; p < HW; p += 64) {
-            const long long bp = (long long)b * HW + p;
-            const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
-            const float xh = (xv - mean) * rstd;
-            float dv = TI<T>::ld(dy, bp * C + c);
-            if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
-            sg += dv * xh; sb += dv;
+        if (pr < npr) {
+            const int c = cg0 + ci;
+            const float gm = gamma[c], bt = beta[c];
+            for (int p = pr; p < HW; p += npr) {
+                const long long bp = (long long)b * HW + p;
+                const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
+                const float xh = (xv - mean) * rstd;
+                float dv = TI<T>::ld(dy, bp * C + c);
+                if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
+                sg += dv * xh; sb += dv;
+            }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
-        if (lane == 0) {
-            dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
-            Sa += gm * sb; Sb += gm * sg;
-        }
+        red[0][tid] = sg; red[1][tid] = sb;
     }
-    if (lane == 0) { wsum[0][wv] = Sa; wsum[1][wv] = Sb; }
     __syncthreads();
-    if (tid == 0) { Sa = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]); Sb = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]); }
-    if (tid == 0) { const float N = (float)gw * (float)HW; msum[0] = Sa / N; msum[1] = Sb / N; }
+    if (tid < gw) {
+        float sg = 0.f, sb = 0.f;
+        for (int r = 0; r < npr; ++r) { sg += red[0][r * gw + tid]; sb += red[1][r * gw + tid]; }
+        const int c = cg0 + tid;
+        dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
+        const float gm = gamma[c];
+        red[0][tid] = gm * sb; red[1][tid] = gm * sg;      // own slot only (r = 0 was read by this thread alone)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float Sa = 0.f, Sb = 0.f;
+        for (int ci = 0; ci < gw; ++ci) { Sa += red[0][ci]; Sb += red[1][ci]; }
+        const float N = (float)gw * (float)HW;
+        msum[0] = Sa / N; msum[1] = Sb / N;
+    }
     __syncthreads();
     const float ma = msum[0], mb = msum[1];
     const int total = HW * gw;
@@ -189,6 +225,24 @@ __global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x
         else { const long long o = bp * C1 + (c - C0); if (acc1) d += TI<T>::ld(dx1, o); TI<T>::st(dx1, o, d); }
     }
 }
+// dgamma[c] (+)= sum_b dgp[b][c], dbeta[c] (+)= sum_b dbp[b][c], both in image order
+__global__ __launch_bounds__(256) void sum_images2_kernel(const float* __restrict__ dgp, const float* __restrict__ dbp, int B, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int accumulate) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * C) return;
+    const int c = id < C ? id : id - C;
+    const float* src = id < C ? dgp : dbp;
+    float* out = id < C ? dgamma : dbeta;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += src[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+// zero two small ranges of 16-bit / 32-bit elements (the margins around the shifted wgrad operand) in one launch
+__global__ __launch_bounds__(256) void zero2_kernel(unsigned char* __restrict__ p0, long long n0, unsigned char* __restrict__ p1, long long n1) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n0) p0[i] = 0; else p1[i - n0] = 0;
+    }
+}
 template <typename T>
 static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, const void* x1, int xs1, int C, int HW, const void* dy, const float* g, const float* bta,
                          const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp) {
@@ -201,11 +255,11 @@ static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
 // typed launch helpers ------------------------------------------------------------------------------------------------
 template <typename T>
 static void gather_t(hipStream_t s, const void* src, int xs, int c_off, int C, int B, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x, void* dst,
-                     int rows_per_img, int kp) {
-    // dst image stride is rows_per_img * kp (rows past C stay as they are: the buffer is zeroed once by the caller where that matters)
-    const long long total = (long long)B * C * kp;
-    hipLaunchKernelGGL(gather_t_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)src + c_off, xs, C, H, W, Ho, Wo, stride, off_y, off_x, (T*)dst,
-                       (long long)rows_per_img * kp, kp, total);
+                     int rows_per_img, int kp, int zero_rows_to = 0) {
+    // dst image stride is rows_per_img * kp; rows C .. zero_rows_to-1 of every image are zero-filled (the GEMM's padded M rows)
+    const int crows = zero_rows_to > C ? zero_rows_to : C;
+    hipLaunchKernelGGL(gather_t_kernel<T>, dim3((kp + 63) / 64, (crows + 63) / 64, B), dim3(256), 0, s, (const T*)src + c_off, xs, C, crows, H, W, Ho, Wo, stride, off_y,
+                       off_x, (T*)dst, (long long)rows_per_img * kp, kp);
 }
 #define BY_DTYPE(dtype, FN, ...) do { if ((dtype) == WDM_BF16) FN<__bf16>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
@@ -219,8 +273,9 @@ template <typename T> static void l_sumpool2(hipStream_t s, const void* dy, int 
     hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)dy, C, h, w, (T*)dx, acc, total);
 }
 template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, int cout, int cin, int kk, void* dst, int rows, int kpad) {
-    const long long total = (long long)kk * rows * kpad;
-    hipLaunchKernelGGL(pack_dgrad_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, w, cout, cin, kk, (T*)dst, rows, kpad);
+    const dim3 grid((kpad + 31) / 32, (rows + 31) / 32);
+    if (kk == 9) hipLaunchKernelGGL((pack_dgrad_kernel<T, 9>), grid, dim3(256), 0, s, w, cout, cin, (T*)dst, rows, kpad);
+    else hipLaunchKernelGGL((pack_dgrad_kernel<T, 1>), grid, dim3(256), 0, s, w, cout, cin, (T*)dst, rows, kpad);
 }
 template <typename T> static void l_pad_channels(hipStream_t s, const void* x, int C, int Cp, void* y, long long total) {
     hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)x, C, Cp, (T*)y, total);
@@ -335,10 +390,9 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
         if (!dyT || !aT3 || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
         if (!c.dry) {
-            WDM_HIP(hipMemsetAsync(dyT, 0, (size_t)c.B * rows_g * kq * es, c.s));
-            WDM_HIP(hipMemsetAsync(aT3, 0, (size_t)Wq * es, c.s));
-            WDM_HIP(hipMemsetAsync(aT3 + ((size_t)Wq + 3 * a_elems) * es, 0, (size_t)Wq * es, c.s));
-            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq);
+            hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c.s, (unsigned char*)aT3, (long long)((size_t)Wq * es),
+                               (unsigned char*)aT3 + ((size_t)Wq + 3 * a_elems) * es, (long long)((size_t)Wq * es));
+            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq, rows_g);
             for (int dx = 0; dx < 3; ++dx) {
                 char* dst = aT3 + ((size_t)Wq + dx * a_elems) * es;
                 BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq);
@@ -372,8 +426,7 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
     if (!dyT || !aT || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
     if (!c.dry) {
-        WDM_HIP(hipMemsetAsync(dyT, 0, (size_t)c.B * rows_g * kp * es, c.s));
-        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp);
+        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp, rows_g);
         const int stride = mode == MODE_S2 ? 2 : 1;
         for (int tap = 0; tap < kk && rc == WDM_OK; ++tap) {
             const int ty = tap / k, tx = tap % k;
@@ -419,14 +472,13 @@ int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, 
 int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
                     bool acc1, float* dgamma, float* dbeta, bool acc_param) {
     const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
-    float* part = (float*)c.ar->alloc(((size_t)2 * c.B * C + (size_t)colsum_chunks(c.B) * C) * sizeof(float));
+    if (C % 32 || C / 32 > 256) WDM_FAIL(WDM_EINVAL, "GroupNorm backward: %d channels unsupported (multiple of 32, <= 8192)", C);
+    float* part = (float*)c.ar->alloc((size_t)2 * c.B * C * sizeof(float));
     if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm backward)");
     if (!c.dry) {
         BY_DTYPE(c.dtype, l_gn_act_bwd, c.s, c.B, x0.p, x0.xs, x0.C, x1 ? x1->p : x0.p, x1 ? x1->xs : 0, C, HW, dy.p, nw.g, nw.b, mean_rstd, silu, dx0, acc0 ? 1 : 0,
                  x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C);
-        float* sc2 = part + (size_t)2 * c.B * C;
-        l_colsum<float>(c.s, part, C, C, c.B, 1, dgamma, acc_param ? 1 : 0, 0, sc2);
-        l_colsum<float>(c.s, part + (size_t)c.B * C, C, C, c.B, 1, dbeta, acc_param ? 1 : 0, 0, sc2);
+        hipLaunchKernelGGL(sum_images2_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, c.s, part, part + (size_t)c.B * C, c.B, C, dgamma, dbeta, acc_param ? 1 : 0);
         WDM_HIP(hipGetLastError());
     }
     c.ar->free(part);
