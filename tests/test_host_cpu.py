@@ -26,6 +26,39 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().wdm_abi_version() == 1
 
 
+def test_ctypes_signatures_agree_with_the_header():
+    """Every prototype of include/wavedm.h against the ctypes binding: same number of arguments, same kind (pointer / int / float /
+    size_t / int64) in the same order, same return kind -- a silent mismatch here would corrupt arguments instead of failing."""
+    hdr = open(os.path.join(REPO, "include", "wavedm.h")).read()
+    hdr = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))
+    protos = re.findall(r"([A-Za-z_][\w\s\*]*?)\b(wdm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(protos) == len(_lib.EXPORTED)
+
+    def kind_c(decl, is_param=True):
+        decl = decl.strip()
+        if decl in ("void", ""):
+            return None
+        if "*" in decl or "[" in decl:
+            return "ptr"
+        words = re.sub(r"\b(const|unsigned|extern|WDM_API)\b", "", decl).split()
+        ty = " ".join(words[:-1]) if (is_param and len(words) > 1) else " ".join(words)
+        return {"int": "int", "float": "float", "size_t": "size_t", "int64_t": "i64", "double": "double"}[ty]
+
+    def kind_py(a):
+        if a is None:
+            return None
+        if a in (C.c_void_p, C.c_char_p) or (isinstance(a, type) and issubclass(a, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "int", C.c_float: "float", C.c_size_t: "size_t", C.c_int64: "i64", C.c_double: "double"}[a]
+
+    L = _lib.lib()
+    for ret, name, params in protos:
+        fn = getattr(L, name)
+        want = [k for k in (kind_c(x) for x in params.split(",")) if k]
+        assert [kind_py(a) for a in fn.argtypes] == want, name
+        assert kind_py(fn.restype) == kind_c(ret, is_param=False), name
+
+
 @pytest.mark.parametrize("cfg", [P.raindrop_wavelet_config(), P.reduced_config(), P.raindrop_wavelet_config(image_size=128)])
 def test_param_table_matches_reference_state_dict_layout(cfg):
     import wavedm_amd
