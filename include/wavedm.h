@@ -237,6 +237,9 @@ int wdm_trainer_num_params(const wdm_trainer* t);
 int64_t wdm_trainer_num_floats(const wdm_trainer* t);
 int wdm_trainer_param_info(const wdm_trainer* t, int i, const char** name, int* ndim, int64_t shape[4], int64_t* offset);
 int wdm_trainer_set_buffers(wdm_trainer* t, float* params, float* grads, float* m, float* v, float* ema);
+/* training.use_mse (ddm_wavelet.py:263-266): back-propagate mse_loss = mean_b sum (x_tar - x0_pred)^2 instead of the noise-space loss
+ * (default 0).  *loss of wdm_trainer_step stays the noise-space value either way. */
+int wdm_trainer_set_objective(wdm_trainer* t, int use_mse);
 int wdm_trainer_step(wdm_trainer* t, const float* x0, const float* tt, const float* sqrt_a, const float* sqrt_1ma, const float* e,
                      int B, int c_t0, float* loss, float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
 int wdm_trainer_adam_ema(wdm_trainer* t, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -508,12 +508,13 @@ def noise_estimation_loss(sd, config, x0, t, e, betas):
     return simple_loss.mean(dim=0), output, x0_pred, mse_loss.mean(dim=0)
 
 
-def train_grads(sd, config, x0, t, e, betas):
-    """loss.backward() of the step above: -> (loss, {name: grad}) by torch autograd over the functional forward."""
+def train_grads(sd, config, x0, t, e, betas, use_mse=False):
+    """loss.backward() of the step above -- mse_loss.backward() with training.use_mse (ddm_wavelet.py:263-266): -> (loss, output,
+    {name: grad}) by torch autograd over the functional forward.  The returned loss is the noise-space one either way."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
     with torch.enable_grad():
-        loss, output, _, _ = noise_estimation_loss(leaf, config, x0, t, e, betas)
-        loss.backward()
+        loss, output, _, mse = noise_estimation_loss(leaf, config, x0, t, e, betas)
+        (mse if use_mse else loss).backward()
     return loss.detach(), output.detach(), {k: v.grad for k, v in leaf.items()}
 
 

@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--only-io", action="store_true", help="regenerate io.npz only")
     ap.add_argument("--only-train", action="store_true", help="regenerate train.npz only")
     ap.add_argument("--only-variants", action="store_true", help="regenerate variants.npz only")
+    ap.add_argument("--only-config", action="store_true", help="regenerate config.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -211,6 +212,20 @@ def main():
             pn, _, _ = O.adam_step(sd_t[k], grads[k], torch.zeros_like(sd_t[k]), torch.zeros_like(sd_t[k]), 1)
             assert rel_err(pn, newp[k].detach()) <= 1e-6, k
             assert rel_err(O.ema_update(sd_t[k], pn), ema.shadow[k]) <= 1e-6, k
+        # training.use_mse: the same step differentiating mse_loss (ddm_wavelet.py:263-264) on a fresh copy of the model
+        net_m = RU.DiffusionUNet(cfg_t).train()
+        net_m.load_state_dict(sd_t, strict=True)
+        _, _, _, mse_m = noise_estimation_loss(net_m, x0, t, e, betas_t, inp_channels=48, pred_channels=3, use_other_channels=True)
+        mse_m.backward()
+        grads_m = {k: p.grad.detach().clone() for k, p in net_m.named_parameters()}
+        _, _, o_gm = O.train_grads(sd_t, cfg_t, x0, t, e, betas_t, use_mse=True)
+        worst = max(rel_err(o_gm[k], grads_m[k]) for k in grads_m)
+        print(f"  oracle vs reference  use_mse: all {len(grads_m)} gradients: worst rel_linf = {worst:.3e}")
+        assert worst <= 1e-4
+        tr["gm_absmax"] = np.array([float(g.abs().max()) for g in grads_m.values()])
+        tr["gm_sum"] = np.array([float(g.double().sum()) for g in grads_m.values()])
+        for k in keep:
+            tr["gm:" + k] = sub(grads_m[k], 1 if grads_m[k].numel() <= 4096 else 13)
         np.savez_compressed(out("train.npz"), **tr)
         torch.set_grad_enabled(False)
 
@@ -235,6 +250,26 @@ def main():
             va[kind] = y.numpy()
         np.savez_compressed(out("variants.npz"), **va)
 
+    # ------------------------------------------------------------------ config file (the YAML keys the drop-in must read)
+    def golden_config():
+        print("[config]")
+        import hashlib
+        import json
+        import yaml
+        from wavedm_amd.config import namespace2dict
+        with open(os.path.join(REF, "configs", "raindrop_wavelet.yml")) as f:
+            ref_cfg = yaml.safe_load(f)
+        mine = namespace2dict(P.raindrop_wavelet_config())
+        mine["data"]["data_dir"], mine["data"]["num_workers"] = ref_cfg["data"]["data_dir"], ref_cfg["data"]["num_workers"]   # deployment keys
+        assert mine == ref_cfg, "procedural.raindrop_wavelet_config() differs from the reference's configs/raindrop_wavelet.yml"
+        canon = json.dumps(ref_cfg, sort_keys=True)
+        np.savez_compressed(out("config.npz"), sha256=np.array(hashlib.sha256(canon.encode()).hexdigest()),
+                            n_keys=np.array(sum(len(v) for v in ref_cfg.values())), sections=np.array(sorted(ref_cfg)))
+        print(f"  procedural config == reference YAML ({sum(len(v) for v in ref_cfg.values())} keys)")
+
+    if args.only_config:
+        golden_config()
+        return
     if args.only_variants:
         golden_variants()
         return
@@ -251,6 +286,7 @@ def main():
     golden_io()
     golden_train()
     golden_variants()
+    golden_config()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")

@@ -90,12 +90,12 @@ def _sub(t):
     return t[:: (1 if t.numel() <= 4096 else 13)]
 
 
-def _trainer(dtype):
+def _trainer(dtype, **kw):
     from wavedm_amd import procedural as P
     from wavedm_amd.training import Trainer
     cfg = P.reduced_config()
     cfg.device = dev()
-    tr = Trainer(cfg, dtype=dtype, lr=4e-5, eps=1e-8)
+    tr = Trainer(cfg, dtype=dtype, lr=4e-5, eps=1e-8, **kw)
     tr.load_state_dict(P.procedural_state_dict(cfg, seed=61))
     return tr, cfg
 
@@ -146,6 +146,26 @@ def test_training_step_matches_reference_golden(golden):
                 continue
             assert rel_linf(_sub(sd[k]).cpu(), torch.from_numpy(g[key])) <= 1e-5, k
             assert rel_linf(_sub(ema[k]).cpu(), torch.from_numpy(g["ema1:" + k])) <= 1e-5, k
+
+
+def test_training_use_mse_matches_reference_golden(golden):
+    """training.use_mse: the x0-space objective's gradients == the reference's mse_loss.backward() (f32 mode); the reported loss stays the
+    noise-space value."""
+    g = golden("train.npz")
+    tr, cfg = _trainer("f32", use_mse=True)
+    x0, e, t = seeded((4, 96, 16, 16), 401).to(dev()), seeded((4, 3, 16, 16), 402).to(dev()), torch.tensor([990, 9, 500, 499])
+    loss = tr.loss_and_grads(x0, t, e)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    grads = tr.grad_dict()
+    floor = 1e-4 * float(g["gm_absmax"].max())
+    for k, amax in zip([str(n) for n in g["grad_names"]], g["gm_absmax"]):
+        assert abs(float(grads[k].abs().max()) - amax) / max(amax, floor) <= 5e-3, k
+    for key in g.files:
+        if key.startswith("gm:"):
+            want = torch.from_numpy(g[key])
+            err = float((_sub(grads[key[3:]]).cpu() - want).abs().max()) / max(float(want.abs().max()), floor)
+            assert err <= 2e-3, (key, err)
+    assert float(g["gm_absmax"].max()) > 3 * float(g["grad_absmax"].max())          # the two objectives really differ on these inputs
 
 
 def test_training_step_bf16_tracks_f32():

@@ -207,3 +207,20 @@ def test_make_grid_matches_torchvision_layout():
         a, b = make_grid(t, nrow=nrow, padding=pad), O.make_grid(t, nrow=nrow, padding=pad)
         assert a.shape == b.shape and torch.equal(a, b)
     assert tuple(make_grid(torch.rand(8, 3, 12, 20), nrow=4).shape) == (3, 2 * 14 + 2, 4 * 22 + 2)
+
+
+def test_config_file_matches_reference_yaml(golden):
+    """configs/raindrop_wavelet.yml (and procedural.raindrop_wavelet_config()) carry every key of the reference's YAML with the same
+    values: the canonical JSON hashes to the value recorded when the golden files were generated from the reference's file."""
+    import hashlib
+    import json
+    from wavedm_amd.config import load_config, namespace2dict, dict2namespace
+    g = golden("config.npz")
+    shipped = namespace2dict(load_config(os.path.join(REPO, "configs", "raindrop_wavelet.yml")))
+    built = namespace2dict(P.raindrop_wavelet_config())
+    for d in (shipped, built):
+        d["data"]["data_dir"], d["data"]["num_workers"] = "/data1/weather/", 32         # the reference file's deployment settings
+        assert sorted(d) == [str(v) for v in g["sections"]] and sum(len(v) for v in d.values()) == int(g["n_keys"])
+        assert hashlib.sha256(json.dumps(d, sort_keys=True).encode()).hexdigest() == str(g["sha256"])
+    ns = dict2namespace(shipped)
+    assert ns.model.ch_mult == [1, 2, 4, 6] and ns.optim.lr == 4e-5 and ns.training.patch_n == 8 and ns.data.wavelet is True

@@ -197,3 +197,18 @@ def test_training_step_matches_reference_golden(golden):
             p1, m1, v1 = O.adam_step(sd[k], grads[k], torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1)
             assert rel_linf(_sub(p1), torch.from_numpy(g["p1:" + k])) <= 1e-6, k
             assert rel_linf(_sub(O.ema_update(sd[k], p1)), torch.from_numpy(g["ema1:" + k])) <= 1e-6, k
+
+
+def test_training_use_mse_matches_reference_golden(golden):
+    """training.use_mse (ddm_wavelet.py:263-264): gradients of mse_loss == the reference's, on the same inputs as above."""
+    g = golden("train.npz")
+    cfg = P.reduced_config()
+    sd = P.procedural_state_dict(cfg, seed=61)
+    x0, e, t = seeded((4, 96, 16, 16), 401), seeded((4, 3, 16, 16), 402), torch.tensor([990, 9, 500, 499])
+    loss, _, grads = O.train_grads(sd, cfg, x0, t, e, O.beta_schedule(cfg), use_mse=True)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))          # the reported loss is the noise-space one
+    for k, amax in zip([str(n) for n in g["grad_names"]], g["gm_absmax"]):
+        assert abs(float(grads[k].abs().max()) - amax) <= 1e-4 * amax + 1e-12, k
+    for key in g.files:
+        if key.startswith("gm:"):
+            assert rel_linf(_sub(grads[key[3:]]), torch.from_numpy(g[key])) <= 1e-5, key

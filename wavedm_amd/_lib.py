@@ -103,6 +103,7 @@ def lib():
         "wdm_trainer_num_floats": (i64, [vp]),
         "wdm_trainer_param_info": (i, [vp, i, C.POINTER(C.c_char_p), C.POINTER(i), C.POINTER(i64 * 4), C.POINTER(i64)]),
         "wdm_trainer_set_buffers": (i, [vp, vp, vp, vp, vp, vp]),
+        "wdm_trainer_set_objective": (i, [vp, i]),
         "wdm_trainer_step": (i, [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]),
         "wdm_trainer_adam_ema": (i, [vp, i64, f, f, f, f, f, f, vp]),
         "wdm_prof_enable": (i, [i]),
@@ -125,7 +126,7 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
-            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_prof_enable", "wdm_prof_report"]
 
 
 def prof_enable(on: bool):

@@ -37,9 +37,13 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
     }
 }
 // loss = sum_b sum (e - out)^2 / B (ddm_wavelet.py:121, :124); dout = 2 (out - e) / B.  out: NHWC fp32 [B][HW][pc]; e: NCHW.
+// sample_w (optional, training.use_mse): the objective that is differentiated is mean_b w_b sum (e - out)^2 with w_b = (1 - abar_t) / abar_t,
+// which is the reference's mse_loss = sum (x_tar - x0_pred)^2 (:120, :122; x_tar - x0_pred = (out - e) sqrt((1 - abar) / abar)); the value
+// written to *loss stays the unweighted one the reference prints and returns.
 template <typename T>
 __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ out, const float* __restrict__ e, int B, int pc, int HW, T* __restrict__ dout,
-                                                    float* __restrict__ loss, float* __restrict__ out_nchw) {
+                                                    float* __restrict__ loss, float* __restrict__ out_nchw, const float* __restrict__ sqrt_a,
+                                                    const float* __restrict__ sqrt_1ma) {
     __shared__ double red[1024];
     const long long total = (long long)B * HW * pc;
     double s = 0.0;
@@ -51,7 +55,9 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ ou
         const long long en = (b * pc + c) * HW + p;
         const float o = out[id], d = o - e[en];
         s += (double)d * d;
-        TI<T>::st(dout, id, 2.0f * d / (float)B);
+        float w = 1.0f;
+        if (sqrt_a) { const float r = sqrt_1ma[b] / sqrt_a[b]; w = r * r; }
+        TI<T>::st(dout, id, 2.0f * w * d / (float)B);
         if (out_nchw) out_nchw[en] = o;
     }
     red[threadIdx.x] = s;
@@ -162,8 +168,9 @@ template <typename T> static void l_build_input(hipStream_t s, const float* x0, 
                                                 long long total) {
     hipLaunchKernelGGL(build_input_kernel<T>, dim3(nb(total, 256)), dim3(256), 0, s, x0, e, sa, s1m, C, HW, c_t0, pc, (T*)x96, total);
 }
-template <typename T> static void l_loss(hipStream_t s, const float* out, const float* e, int B, int pc, int HW, void* dout, float* loss, float* out_nchw) {
-    hipLaunchKernelGGL(loss_kernel<T>, dim3(1), dim3(1024), 0, s, out, e, B, pc, HW, (T*)dout, loss, out_nchw);
+template <typename T> static void l_loss(hipStream_t s, const float* out, const float* e, int B, int pc, int HW, void* dout, float* loss, float* out_nchw,
+                                         const float* sqrt_a, const float* sqrt_1ma) {
+    hipLaunchKernelGGL(loss_kernel<T>, dim3(1), dim3(1024), 0, s, out, e, B, pc, HW, (T*)dout, loss, out_nchw, sqrt_a, sqrt_1ma);
 }
 // transposed copy used by the attention backward: dst[b][c][n] = src[b][n][c]   (train.hip's gather with stride 1, offset 0)
 int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst);
@@ -189,6 +196,7 @@ struct wdm_trainer {
     std::vector<PInfo> params;
     size_t nfloats = 0;
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *E = nullptr;
+    bool use_mse = false;     // training.use_mse: differentiate the x0-space loss instead of the noise-space one
     // layers
     size_t d0w, d0b, d1w, d1b, tw, tb;
     ConvP conv_in, conv_out;
@@ -519,7 +527,7 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     // ---- loss and its gradient
     void* dout = cc.ar->alloc((size_t)B * R * R * pc * es);
     if (!dout) WDM_FAIL(WDM_ENOMEM, "training workspace too small (loss gradient)");
-    BYT(cc.dtype, l_loss, cc.s, outf, e, B, pc, R * R, dout, loss, out_nchw);
+    BYT(cc.dtype, l_loss, cc.s, outf, e, B, pc, R * R, dout, loss, out_nchw, use_mse ? sa : nullptr, use_mse ? s1m : nullptr);
     // ---- backward: conv_out by hand, then the tape in reverse
     {
         Tens dy; dy.p = dout; dy.C = pc; dy.H = R; dy.W = R; dy.xs = pc;
@@ -584,6 +592,11 @@ int wdm_trainer_param_info(const wdm_trainer* t, int i, const char** name, int* 
 int wdm_trainer_set_buffers(wdm_trainer* t, float* params, float* grads, float* m, float* v, float* ema) {
     if (!t || !params || !grads) WDM_FAIL(WDM_EINVAL, "wdm_trainer_set_buffers: params and grads are required");
     t->P = params; t->G = grads; t->M = m; t->V = v; t->E = ema;
+    return WDM_OK;
+}
+int wdm_trainer_set_objective(wdm_trainer* t, int use_mse) {
+    if (!t) WDM_FAIL(WDM_EINVAL, "wdm_trainer_set_objective: null trainer");
+    t->use_mse = use_mse != 0;
     return WDM_OK;
 }
 int wdm_trainer_step(wdm_trainer* t, const float* x0, const float* tt, const float* sqrt_a, const float* sqrt_1ma, const float* e, int B, int c_t0, float* loss,

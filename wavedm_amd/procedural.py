@@ -35,7 +35,8 @@ def dict2namespace(d):
 
 def raindrop_wavelet_config(image_size: int = 64, ch: int = 128, ch_mult=(1, 2, 4, 6),
                             num_res_blocks: int = 2, attn_resolutions=(16,)):
-    """The keys of `configs/raindrop_wavelet.yml` that the sampling path reads."""
+    """Every key of `configs/raindrop_wavelet.yml` with its values (checked against the reference's file by tests/golden/make_golden.py),
+    except the two deployment-specific ones: data.data_dir ("" here) and data.num_workers (0 here)."""
     return dict2namespace({
         "data": {"dataset": "RainDrop", "image_size": image_size, "patch_size": image_size * 4,
                  "lap": False, "global_attn": False, "wavelet": True, "wavelet_in_unet": False,
@@ -48,7 +49,10 @@ def raindrop_wavelet_config(image_size: int = 64, ch: int = 128, ch_mult=(1, 2, 
                   "ema": True, "resamp_with_conv": True},
         "diffusion": {"beta_schedule": "linear", "beta_start": 0.0001, "beta_end": 0.02,
                       "num_diffusion_timesteps": 1000},
+        "training": {"use_mse": False, "patch_n": 8, "batch_size": 1, "n_epochs": 38000, "n_iters": 2000000,
+                     "snapshot_freq": 3000, "validation_freq": 3000},
         "sampling": {"batch_size": 1, "last_only": True},
+        "optim": {"weight_decay": 0.0, "optimizer": "Adam", "lr": 0.00004, "amsgrad": False, "eps": 0.00000001},
     })
 
 

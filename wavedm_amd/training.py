@@ -21,7 +21,7 @@ from .unet import _make_config, resolve_dtype
 
 
 class Trainer:
-    def __init__(self, config, device=None, dtype=None, lr=None, betas=(0.9, 0.999), eps=None, weight_decay=None, ema_mu=0.9999):
+    def __init__(self, config, device=None, dtype=None, lr=None, betas=(0.9, 0.999), eps=None, weight_decay=None, ema_mu=0.9999, use_mse=None):
         self.config = config
         self.device = torch.device(device if device is not None else getattr(config, "device", "cuda:0"))
         if self.device.type != "cuda":
@@ -32,6 +32,10 @@ class Trainer:
         self.eps = float(eps if eps is not None else getattr(opt, "eps", 1e-8))
         self.weight_decay = float(weight_decay if weight_decay is not None else getattr(opt, "weight_decay", 0.0))
         self.betas, self.ema_mu = (float(betas[0]), float(betas[1])), float(ema_mu)
+        if opt is not None and (getattr(opt, "optimizer", "Adam") != "Adam" or getattr(opt, "amsgrad", False)):
+            raise NotImplementedError("wavedm_amd.Trainer implements optim.optimizer: Adam with amsgrad: False (utils/optimize.py:6-8, raindrop_wavelet.yml)")
+        # training.use_mse (ddm_wavelet.py:263-266): back-propagate the x0-space loss instead of the noise-space one
+        self.use_mse = bool(use_mse if use_mse is not None else getattr(getattr(config, "training", None), "use_mse", False))
         L = _lib.lib()
         self._cfg = _make_config(config, self._dtype_code)
         t = C.c_void_p()
@@ -49,6 +53,7 @@ class Trainer:
             self.exp_avg = torch.zeros(n, device=self.device)
             self.exp_avg_sq = torch.zeros(n, device=self.device)
             self.ema = torch.zeros(n, device=self.device)
+        _lib.check(L.wdm_trainer_set_objective(t, 1 if self.use_mse else 0))
         _lib.check(L.wdm_trainer_set_buffers(t, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.ema)))
         betas_t = sampling.get_beta_schedule(beta_schedule=config.diffusion.beta_schedule, beta_start=config.diffusion.beta_start,
                                              beta_end=config.diffusion.beta_end, num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
