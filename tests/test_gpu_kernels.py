@@ -61,7 +61,7 @@ def test_dwt_golden_and_properties(gu, O, golden):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("mode,cin,cout,B,H", [
     (0, 64, 128, 2, 16), (0, 96, 128, 1, 32), (0, 128, 3, 2, 16), (0, 64, 64, 3, 8), (0, 128, 3, 1, 8),
-    (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16),
+    (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16), (2, 96, 160, 3, 16), (2, 256, 256, 2, 32),
     (3, 64, 128, 2, 16), (3, 160, 64, 3, 8), (3, 384, 128, 1, 32),
 ])
 def test_conv_modes(gu, O, dtype, mode, cin, cout, B, H):
@@ -75,6 +75,33 @@ def test_conv_modes(gu, O, dtype, mode, cin, cout, B, H):
     got = gu.conv(w, b, mode, x, dtype)
     assert got.shape == ref.shape
     assert rel_linf(got, ref) <= gu.TOL[dtype], (mode, cin, cout, B, H)
+
+
+def test_subpixel_upsample_equals_nine_tap_kernel(gu, O):
+    """bf16 Upsample convs run as four 2x2-tap phase convolutions on the low-resolution map (conv_up4_kernel.h); WDM_UP4=0 keeps the
+    9-tap kernel on the upsampled grid.  Same inputs through both: they differ only by the rounding of the pre-summed weights."""
+    import os
+    w = gu.seeded((160, 96, 3, 3), 11) / (96 * 9) ** 0.5
+    b = gu.seeded((160,), 12) * 0.1
+    x = gu.seeded((3, 96, 16, 16), 13)
+    ref = O.upsample({"c.conv.weight": w, "c.conv.bias": b}, "c", x)
+    old = os.environ.get("WDM_UP4")
+    try:
+        os.environ["WDM_UP4"] = "1"
+        y4 = gu.conv(w, b, 2, x, "bf16")
+        os.environ["WDM_UP4"] = "0"
+        y9 = gu.conv(w, b, 2, x, "bf16")
+    finally:
+        if old is None:
+            os.environ.pop("WDM_UP4", None)
+        else:
+            os.environ["WDM_UP4"] = old
+    e4, e9 = rel_linf(y4, ref), rel_linf(y9, ref)
+    assert e4 <= 2e-2 and e9 <= 2e-2 and rel_linf(y4, y9) <= 2e-2, (e4, e9)
+    assert not torch.equal(y4, y9)                       # two different kernels really ran
+    # borders: the zero padding of the upsampled map == the zero padding of the low-resolution one
+    for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+        assert rel_linf(y4[sl], ref[sl]) <= 2e-2
 
 
 # ----------------------------------------------------------------------------------------- blocks vs golden + oracle

@@ -75,6 +75,13 @@ static int alloc_f32(Ctx& c, size_t n, float** p) {
     return WDM_OK;
 }
 
+// The sub-pixel Upsample kernel (conv_up4_kernel.h) takes bf16 maps whose LOW-resolution size is a multiple of its 16 x 16 tile; WDM_UP4=0
+// keeps the 9-tap kernel everywhere (A/B runs)
+bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
+    const char* e = getenv("WDM_UP4");                 // read per call (three Upsample convs per UNet pass): tests flip it in-process
+    return !(e && e[0] == '0') && dtype == WDM_BF16 && H % 16 == 0 && W % 16 == 0 && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+}
+
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
     return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : launch_conv_f32(a, mode, s);
 }
@@ -109,6 +116,12 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
     a.res = res ? res->p : nullptr; a.res_s = res ? res->xs : 0;
     a.y = y; a.y_mode = y_mode; a.y_s = w.cout;
+    if (mode == MODE_UPS && w.w_up4 && !x1 && !scale && !temb && !res && !shortcut && y_mode == Y_NHWC && conv_up4_eligible(c.dtype, x0.H, x0.W, Cin, w.cout)) {
+        mode = MODE_UP4;                                  // same result from 4 pre-summed taps per output phase on the low-resolution map
+        a.Hout = x0.H; a.Wout = x0.W;
+        a.w = w.w_up4;
+        a.w_bytes = (unsigned)((size_t)16 * w.rows_pad * w.cin * dsize(c.dtype));
+    }
     if (shortcut) {      // 1x1 conv over [sx0 | sx1] accumulated into the same tile
         a.sx0 = sx0->p; a.sx1 = sx1 ? sx1->p : nullptr;
         a.sC0 = sx0->C; a.sC1 = sx1 ? sx1->C : 0; a.sxs0 = sx0->xs; a.sxs1 = sx1 ? sx1->xs : 0;

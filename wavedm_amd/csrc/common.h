@@ -75,6 +75,7 @@ struct Ctx {
 // ---- packed parameter views (device pointers) -------------------------------------------------
 struct ConvW {
     const void* w = nullptr;   // [taps][rows_pad][cin] model dtype
+    const void* w_up4 = nullptr;   // Upsample convs, bf16: the 16 pre-summed sub-pixel taps (k_pack_up4), or nullptr
     const float* b = nullptr;  // [cout]
     int cin = 0, cout = 0, k = 1, rows_pad = 0;
 };
@@ -136,6 +137,8 @@ int k_linear(const float* in, int n, int k, const float* W, const float* b, int 
 // cin_dst > cin: destination rows are cin_dst long, the extra columns zero (0 = cin)
 int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail,
                 int dtype, hipStream_t s, int cin_dst = 0);
+int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s);
+bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout);      // sub-pixel Upsample kernel applies to this low-resolution map
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
 

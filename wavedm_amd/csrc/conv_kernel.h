@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned short bf16_raw;
 
-enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UPS = 2, MODE_P1 = 3 };
+enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UPS = 2, MODE_P1 = 3, MODE_UP4 = 4 };   // MODE_UP4: conv_up4_kernel.h (host-side selection only)
 enum { Y_NHWC = 0, Y_NCHW = 1, Y_NCHW_F32 = 2, Y_NHWC_F32 = 3 };
 
 struct ConvArgs {
@@ -97,6 +97,9 @@ struct ConvArgs {
     //   w + b * w_img_stride + (tap % 3) * w_tx_stride + (tap / 3 - 1) * w_ty_stride        (img_mod == 0: off)
     int img_mod;
     long long w_tx_stride, w_ty_stride;
+    // sub-pixel form of Upsample (conv_up4_kernel.h): the grid is the LOW-resolution map, N tile nt belongs to output phase nt / up4_ntp
+    // (py = phase >> 1, px = phase & 1) and writes pixel (2 oy + py, 2 ox + px) of the (2 Hout) x (2 Wout) output
+    int up4, up4_ntp;
 };
 
 // element offset of the weight matrix image `img` reads, and the image whose input it reads
@@ -202,7 +205,7 @@ __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { re
 
 template <typename T, int TH, int TW, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
-                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img) {
+                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
     constexpr int VEC = TI<T>::VEC;
     constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
     constexpr int ECOLS = 16 * NJ;
@@ -284,7 +287,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
-                const long long opix = ((long long)(valid ? img_g : 0) * a.Hout + oy) * a.Wout + ox;
+                const long long opix = !a.up4 ? ((long long)(valid ? img_g : 0) * a.Hout + oy) * a.Wout + ox
+                                              : ((long long)(valid ? img_g : 0) * (2 * a.Hout) + 2 * oy + (phase >> 1)) * (2 * a.Wout) + 2 * ox + (phase & 1);
                 if (valid) {
                     if (!TEMB_IN_ADD && a.temb != nullptr) {
                         const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
@@ -354,7 +358,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 const int m0 = wave_m * EROWS + srow;
                 const int img_g = img0 + m0 / (TH * TW);
                 constexpr int SPT = (TH * TW) / SROWS;                    // slabs per tile per image
-                const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS;
+                const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
                 const int nn = ncol0 + col;
                 if ((r0 % SROWS) == 0 && nn < a.Cout && img_g < a.B)
                     ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, (float)SROWS);

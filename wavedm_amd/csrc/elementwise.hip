@@ -535,6 +535,33 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
+// Upsample in sub-pixel form (conv_up4_kernel.h): OIHW f32 3x3 -> [phase = 2 py + px][dy'][dx'][rows_total][cin] bf16, the taps of the
+// upsampled grid that fall on the same low-resolution pixel summed in fp32:  py = 0: {w0}, {w1 + w2};  py = 1: {w0 + w1}, {w2}
+__global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__ w, int cout, int cin, __bf16* __restrict__ dst, int rows_total) {
+    const long long total = (long long)16 * rows_total * cin;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(id % cin);
+        const int o = (int)((id / cin) % rows_total);
+        const int t = (int)(id / ((long long)cin * rows_total));       // phase * 4 + dy' * 2 + dx'
+        const int py = t >> 3, px = (t >> 2) & 1, dyl = (t >> 1) & 1, dxl = t & 1;
+        float v = 0.f;
+        if (o < cout) {
+            const float* p = w + ((long long)o * cin + ci) * 9;
+            const int y0 = py == 0 ? (dyl == 0 ? 0 : 1) : (dyl == 0 ? 0 : 2), y1 = py == 0 ? (dyl == 0 ? 0 : 2) : (dyl == 0 ? 1 : 2);
+            const int x0 = px == 0 ? (dxl == 0 ? 0 : 1) : (dxl == 0 ? 0 : 2), x1 = px == 0 ? (dxl == 0 ? 0 : 2) : (dxl == 0 ? 1 : 2);
+            for (int ty = y0; ty <= y1; ++ty)
+                for (int tx = x0; tx <= x1; ++tx) v += p[ty * 3 + tx];
+        }
+        dst[id] = (__bf16)v;
+    }
+}
+int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s) {
+    const long long total = (long long)16 * rows_total * cin;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    hipLaunchKernelGGL(pack_up4_kernel, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst, rows_total);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
 // y[row][0..Cp) = x[row][0..C) followed by zeros (dense rows)
 template <typename T>
 __global__ __launch_bounds__(256) void pad_channels2_kernel(const T* __restrict__ x, int C, int Cp, T* __restrict__ y, long long total) {

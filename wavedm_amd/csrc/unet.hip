@@ -27,11 +27,12 @@ struct ParamSlot {
     int row_off = 0;      // PK_CONV: first destination row;  PK_F32: element offset inside the destination vector
     bool zero_tail = true;   // PK_CONV: this slot also zero-fills the padding rows behind it
     int cin_dst = 0;         // PK_CONV: row length of the destination when it is padded beyond shape[1] (conv_in), else 0
+    size_t up4_off = 0;      // PK_CONV of an Upsample conv (bf16): second destination, the 16 sub-pixel taps (k_pack_up4); 0 = none
     bool loaded = false;
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 };
 
-struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; };
+struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; size_t up4_off; };
 struct NormD { size_t g_off, b_off; int c; };
 struct ResD { int cin, cout; NormD n1, n2; ConvD c1, c2, nin; bool has_nin; int temb_row; };
 struct AttnD { int c; NormD n; ConvD qk, v, proj; };
@@ -123,7 +124,7 @@ struct wdm_unet {
     }
 
     int build();
-    ConvW cw(const ConvD& d) const { ConvW w; w.w = packed + d.w_off; w.b = (const float*)(packed + d.b_off); w.cin = d.cin; w.cout = d.cout; w.k = d.k; w.rows_pad = d.rows_pad; return w; }
+    ConvW cw(const ConvD& d) const { ConvW w; w.w = packed + d.w_off; w.w_up4 = d.up4_off ? packed + d.up4_off : nullptr; w.b = (const float*)(packed + d.b_off); w.cin = d.cin; w.cout = d.cout; w.k = d.k; w.rows_pad = d.rows_pad; return w; }
     NormW nw(const NormD& d) const { NormW n; n.g = (const float*)(packed + d.g_off); n.b = (const float*)(packed + d.b_off); n.c = d.c; return n; }
     ResW rw(const ResD& d, const float* temb_all, int n_t) const {
         ResW r;
@@ -187,6 +188,10 @@ int wdm_unet::build() {
             for (int b = 0; b <= nrb; ++b) up_attn[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != 0) {
             up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3);
+            if (cfg.dtype == WDM_BF16 && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h, next to the 3x3 ones
+                up_us[l].up4_off = take((size_t)16 * up_us[l].rows_pad * block_in * 2);
+                params[index["up." + std::to_string(l) + ".upsample.conv.weight"]].up4_off = up_us[l].up4_off;
+            }
             res *= 2;
         }
     }
@@ -367,6 +372,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
+        if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s));
     } else {
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
     }
