@@ -61,7 +61,7 @@ def test_dwt_golden_and_properties(gu, O, golden):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("mode,cin,cout,B,H", [
     (0, 64, 128, 2, 16), (0, 96, 128, 1, 32), (0, 128, 3, 2, 16), (0, 64, 64, 3, 8), (0, 128, 3, 1, 8),
-    (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16), (2, 96, 160, 3, 16), (2, 256, 256, 2, 32),
+    (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16), (2, 96, 160, 3, 16), (2, 256, 256, 2, 32), (2, 128, 128, 5, 8), (2, 96, 136, 4, 8),
     (3, 64, 128, 2, 16), (3, 160, 64, 3, 8), (3, 384, 128, 1, 32),
 ])
 def test_conv_modes(gu, O, dtype, mode, cin, cout, B, H):
@@ -77,13 +77,14 @@ def test_conv_modes(gu, O, dtype, mode, cin, cout, B, H):
     assert rel_linf(got, ref) <= gu.TOL[dtype], (mode, cin, cout, B, H)
 
 
-def test_subpixel_upsample_equals_nine_tap_kernel(gu, O):
+@pytest.mark.parametrize("B,H", [(3, 16), (6, 8)])
+def test_subpixel_upsample_equals_nine_tap_kernel(gu, O, B, H):
     """bf16 Upsample convs run as four 2x2-tap phase convolutions on the low-resolution map (conv_up4_kernel.h); WDM_UP4=0 keeps the
     9-tap kernel on the upsampled grid.  Same inputs through both: they differ only by the rounding of the pre-summed weights."""
     import os
     w = gu.seeded((160, 96, 3, 3), 11) / (96 * 9) ** 0.5
     b = gu.seeded((160,), 12) * 0.1
-    x = gu.seeded((3, 96, 16, 16), 13)
+    x = gu.seeded((B, 96, H, H), 13)
     ref = O.upsample({"c.conv.weight": w, "c.conv.bias": b}, "c", x)
     old = os.environ.get("WDM_UP4")
     try:

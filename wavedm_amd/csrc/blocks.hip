@@ -75,11 +75,11 @@ static int alloc_f32(Ctx& c, size_t n, float** p) {
     return WDM_OK;
 }
 
-// The sub-pixel Upsample kernel (conv_up4_kernel.h) takes bf16 maps whose LOW-resolution size is a multiple of its 16 x 16 tile; WDM_UP4=0
+// The sub-pixel Upsample kernel (conv_up4_kernel.h) takes bf16 maps whose LOW-resolution size is a multiple of its 16 x 16 tile, or 8 x 8 (four images per tile); WDM_UP4=0
 // keeps the 9-tap kernel everywhere (A/B runs)
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
     const char* e = getenv("WDM_UP4");                 // read per call (three Upsample convs per UNet pass): tests flip it in-process
-    return !(e && e[0] == '0') && dtype == WDM_BF16 && H % 16 == 0 && W % 16 == 0 && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+    return !(e && e[0] == '0') && dtype == WDM_BF16 && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
 }
 
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {

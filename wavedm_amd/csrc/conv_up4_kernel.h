@@ -17,22 +17,29 @@
 
 namespace wdm {
 
+// TILE x TILE low-resolution pixels of NI images per workgroup: (16, 1) for maps that are multiples of 16, (8, 4) for 8 x 8 maps
+// (one image per wave row: the 64 rows of a wave tile are one image)
+template <int TILE, int NI_>
 struct ConvUp4Cfg {
-    static constexpr int TH = 16, TW = 16, WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4;
+    static constexpr int TH = TILE, TW = TILE, NI = NI_, WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4;
     static constexpr int NWAVES = 8, NTHREADS = 512, BN = 128, BK = 32;
-    static constexpr int A_CPW = 4, B_CPW = 2;                  // 1 KB DMA pieces per wave: halo slab (32) / weight sub-stage (16)
-    static constexpr int PH = 18, PW = 18, RS = 24;
-    static constexpr int A_ROWS = PH * RS;
-    static constexpr int A_BYTES = 32 * 1024;
+    static_assert(TH * TW * NI == 256 && (NI == 1 || TH * TW == 16 * WM), "256-row tile; multi-image tiles: one image per wave row");
+    static constexpr int PH = TH + 2, PW = TW + 2, RS = (PW + 7) / 8 * 8;
+    static constexpr int PLANE_IMG = PH * RS;                   // halo row slots per image: 432 / 160
+    static constexpr int A_ROWS = NI * PLANE_IMG;               // 432 / 640
+    static constexpr int A_CPW = (A_ROWS + 127) / 128, B_CPW = 2;   // 1 KB DMA pieces per wave: halo slab (16 row slots each) / weight sub-stage (16)
+    static constexpr int A_BYTES = A_CPW * 8 * 1024;            // 32 KB / 40 KB
     static constexpr int B_SUB = 2 * BN * 64;                   // 16 KB
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 112 KB
+    static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 112 KB / 128 KB
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
-    static_assert(EPI_BYTES <= LDS_BYTES, "epilogue tile");
+    static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+template <int TILE, int NI_>
 __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
-    using C = ConvUp4Cfg;
+    using C = ConvUp4Cfg<TILE, NI_>;
+    constexpr int NI = C::NI;
     using T = __bf16;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,11 +67,16 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
     const int phase = nt / a.up4_ntp;
     const int py = phase >> 1, px = phase & 1;
     const int n0 = (nt - phase * a.up4_ntp) * BN;
-    const int twn = a.Wout / TW;
-    const int tpi = (a.Hout / TH) * twn;
-    const int img0 = mt / tpi;
-    const int tile_in_img = mt - img0 * tpi;
-    const int oy0 = (tile_in_img / twn) * TH, ox0 = (tile_in_img % twn) * TW;
+    int img0, tile_in_img = 0, oy0 = 0, ox0 = 0;
+    if (NI == 1) {
+        const int twn = a.Wout / TW;
+        const int tpi = (a.Hout / TH) * twn;
+        img0 = mt / tpi;
+        tile_in_img = mt - img0 * tpi;
+        oy0 = (tile_in_img / twn) * TH; ox0 = (tile_in_img % twn) * TW;
+    } else {
+        img0 = mt * NI;
+    }
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -89,10 +101,11 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < ACP; ++i) {
         const int q = (wave * ACP + i) * 16 + (lane >> 2);
-        const int hy = q / RS, hx = q - hy * RS;
+        const int im = q / C::PLANE_IMG, qi = q - im * C::PLANE_IMG;
+        const int hy = qi / RS, hx = qi - hy * RS;
         const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool ok = q < C::A_ROWS && hx < C::PW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-        const unsigned gp = (unsigned)((img0 * a.Hin + iy) * a.Win + ix);
+        const bool ok = q < C::A_ROWS && hx < C::PW && img0 + im < a.B && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const unsigned gp = (unsigned)(((img0 + im) * a.Hin + iy) * a.Win + ix);
         a_v0[i] = ok ? gp * (unsigned)(a.xs0 * 2) + (unsigned)(un * 16) : OOB;
     }
 #pragma unroll
@@ -118,12 +131,17 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
     };
 
     const int ku = lane >> 4;
-    int a_addr[2];
-    {
-        const int m = wave_m * WM * 16 + (lane & 15);
-        const int ly = m / TW, lx = m % TW;
+    // fragment row (wave row group i, tap row dy') of tap column dx': 16-wide tiles -> halo row ly + i + dy' of one address per dx';
+    // 8-wide tiles -> a 16-row group covers two image rows, one address per (i, dx'), dy' is a row-stride offset
+    constexpr int NAI = (TW == 16) ? 1 : WM;
+    int a_addr[NAI][2];
 #pragma unroll
-        for (int dxl = 0; dxl < 2; ++dxl) a_addr[dxl] = lds_off((ly + py) * RS + lx + px + dxl, ku);
+    for (int i = 0; i < NAI; ++i) {
+        const int m = (wave_m * WM + i) * 16 + (lane & 15);
+        const int im = m / (TH * TW), r = m % (TH * TW);
+        const int ly = r / TW, lx = r % TW;
+#pragma unroll
+        for (int dxl = 0; dxl < 2; ++dxl) a_addr[i][dxl] = lds_off(im * C::PLANE_IMG + (ly + py) * RS + lx + px + dxl, ku);
     }
     int b_addr[WN];
 #pragma unroll
@@ -136,20 +154,35 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto mfma_sub = [&](int s, int dxl, int ring) __attribute__((always_inline)) {
-        const char* pa = smem + (s & 1) * C::A_BYTES + a_addr[dxl];
+        const char* pa = smem + (s & 1) * C::A_BYTES;
         const char* pb = smem + ring * C::B_SUB;
-        uint4 ah[WM + 1];
+        if (TW == 16) {
+            uint4 ah[WM + 1];
 #pragma unroll
-        for (int r = 0; r < WM + 1; ++r) ah[r] = *(const uint4*)(pa + r * (RS * 64));
+            for (int r = 0; r < WM + 1; ++r) ah[r] = *(const uint4*)(pa + a_addr[0][dxl] + r * (RS * 64));
 #pragma unroll
-        for (int dyl = 0; dyl < 2; ++dyl) {
-            uint4 bfr[WN];
+            for (int dyl = 0; dyl < 2; ++dyl) {
+                uint4 bfr[WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
+                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], ah[i + dyl], bfr[j]);
+                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], ah[i + dyl], bfr[j]);
+            }
+        } else {
+#pragma unroll
+            for (int dyl = 0; dyl < 2; ++dyl) {
+                uint4 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(pa + a_addr[i % NAI][dxl] + dyl * (RS * 64));
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+            }
         }
     };
 #define WDM_UP4_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
