@@ -18,9 +18,11 @@ static inline int nblk(long long n, int bs) { long long g = (n + bs - 1) / bs; r
 // dst[b][c][k] (row length kp, k = oy*Wo + ox; image stride dst_img elements) = src[b][stride*oy + off_y][stride*ox + off_x][c]
 // (0 outside the map / past Ho*Wo); rows C <= c < Crows are written as zeros.  A 64-channel x 64-position tile per workgroup goes
 // through LDS, so the reads run along the channels of a pixel and the writes along the positions of a channel: both coalesced.
+// Bg > 1: the images are laid out in groups of Bg along the row -- dst[b / Bg][c][b % Bg][k], dst_img = elements per GROUP -- so that a GEMM
+// over a row contracts the pixels of Bg images at once (conv_wgrad).
 template <typename T>
 __global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int C, int Crows, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
-                                                       T* __restrict__ dst, long long dst_img, int kp) {
+                                                       T* __restrict__ dst, long long dst_img, int kp, int Bg) {
     __shared__ float tile[64][65];
     const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const long long b = blockIdx.z;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src
     for (int j = ty; j < 64; j += 4) {
         const int c = c0 + j;
         if (c >= Crows) break;
-        TI<T>::st(dst, b * dst_img + (long long)c * kp + k, c0 < C ? tile[tx][j] : 0.f);
+        TI<T>::st(dst, (b / Bg) * dst_img + ((long long)c * Bg + (b % Bg)) * kp + k, c0 < C ? tile[tx][j] : 0.f);
     }
 }
 // grad[co][ci][tap] (OIHW f32) (+)= sum_b partial[tap][b][co][ci]   (rows_g rows per image in the partial buffer)
@@ -77,15 +79,22 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
     __syncthreads();
     if (sl == 0 && c < C) part[((long long)g * nchunks + ch) * C + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
+// 64 channels x 4 chunk slices per workgroup; the four slice sums are added in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int C, int nchunks, int groups, float* __restrict__ out, int out_ld,
                                                            int accumulate) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= groups * C) return;
-    const int g = id / C, c = id - g * C;
+    __shared__ float red[256];
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[((long long)g * nchunks + k) * C + c];
-    const long long o = (long long)g * out_ld + c;
-    out[o] = accumulate ? out[o] + s : s;
+    if (c < C)
+        for (int k = sl; k < nchunks; k += 4) s += part[((long long)g * nchunks + k) * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        const long long o = (long long)g * out_ld + c;
+        out[o] = accumulate ? out[o] + t : t;
+    }
 }
 // Downsample dgrad helper: z[b][2oy+1][2ox+1][c] = dy[b][oy][ox][c], zero elsewhere (z is H x W, dy is H/2 x W/2)
 template <typename T>
@@ -158,71 +167,144 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__
     }
 }
 
-// ---- GroupNorm (+ SiLU) backward (unet.py:31-37 under autograd).  One workgroup per (group, image).
+// ---- GroupNorm (+ SiLU) backward (unet.py:31-37 under autograd), three passes with full-row 16-byte accesses:
 //   xh = (x - mean) rstd,  pre = xh g + b,  y = silu(pre) (or pre);   dv = dy * silu'(pre)
-//   dgamma_c = sum dv xh,  dbeta_c = sum dv   (per image here; summed over the batch by colsum afterwards)
-//   dx = rstd (dv g - mean_G(dv g) - xh mean_G(dv g xh)),   the group means being sum_c g_c dbeta_c / N and sum_c g_c dgamma_c / N
+//   (1) sums:     per (image, pixel slab, channel)  sum dv xh  and  sum dv                       [gn_bwd_sums_kernel]
+//   (2) finalize: per (image, group) add the slabs in order -> dgamma_c, dbeta_c of the image (summed over the batch afterwards) and the
+//                 group means  ma = sum_c g_c dbeta_c / N,  mb = sum_c g_c dgamma_c / N                [gn_bwd_finalize_kernel]
+//   (3) apply:    dx = rstd (dv g - ma - xh mb)                                                    [gn_bwd_apply_kernel]
 // x = [x0 | x1] (channel concat), dy dense [B][HW][C]; dx0 / dx1 dense per source, optionally accumulated into.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_act_bwd_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
-                                                         const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ mean_rstd, int silu, T* __restrict__ dx0, int acc0, T* __restrict__ dx1, int acc1,
-                                                         float* __restrict__ dgam_part, float* __restrict__ dbet_part) {
-    __shared__ float red[2][256];
-    __shared__ float msum[2];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int gw = C / 32, cg0 = g * gw, C1 = C - C0;
-    const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
-    // phase 1: thread = (pixel row pr, channel ci of the group), ci fastest, so a wave reads runs of gw contiguous channels; every thread
-    // sums its channel over the pixels pr, pr + npr, ...; the npr partial sums of a channel are then added in order
-    const int npr = 256 / gw;                         // gw <= 256, checked by the host
-    {
-        const int ci = tid % gw, pr = tid / gw;
-        float sg = 0.f, sb = 0.f;
-        if (pr < npr) {
-            const int c = cg0 + ci;
-            const float gm = gamma[c], bt = beta[c];
-            for (int p = pr; p < HW; p += npr) {
+__device__ __forceinline__ void gn_bwd_load(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, const T* __restrict__ dy, long long bp,
+                                            int c, const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd, int silu, float* xh,
+                                            float* dv) {
+    constexpr int VEC = TI<T>::VEC;
+    const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+    const uint4 ud = *(const uint4*)(dy + bp * C + c);
+    TI<T>::unpack(ux, xh);
+    TI<T>::unpack(ud, dv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        xh[e] = (xh[e] - mean) * rstd;
+        if (silu) { const float pre = xh[e] * gamma[c + e] + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv[e] *= sgm * (1.0f + pre * (1.0f - sgm)); }
+    }
+}
+// grid (nslab, B, column blocks): 256 threads = (pixel rows) x (16-byte channel vectors); partial[b][slab][c] = {sum dv xh, sum dv}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW, int nslab,
+                                                          const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean_rstd, int silu, float2* __restrict__ partial) {
+    constexpr int VEC = TI<T>::VEC;
+    __shared__ float red[256 * VEC * 2];
+    const int cols = C / VEC;
+    const int cb = blockIdx.z;
+    const int cols_here = min(cols - cb * 256, 256);
+    const int rows = 256 / cols_here;
+    const int tid = threadIdx.x;
+    const int col = tid % cols_here, row = tid / cols_here;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int pps = HW / nslab;
+    const int p0 = slab * pps, p1 = (slab == nslab - 1) ? HW : p0 + pps;
+    const int c = (cb * 256 + col) * VEC;
+    const int gw = C / 32;
+    float sg[VEC], sb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+    if (row < rows) {
+        const int g = c / gw;                                    // VEC divides gw (C % 256 == 0 for bf16, % 128 for f32) or the vector straddles: per element below
+        for (int p = p0 + row; p < p1; p += rows) {
+            float xh[VEC], dv[VEC];
+            if ((c + VEC - 1) / gw == g) {
+                const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
+                gn_bwd_load<T>(x0, xs0, C0, x1, xs1, C, dy, (long long)b * HW + p, c, gamma, beta, mean, rstd, silu, xh, dv);
+            } else {                                             // group boundary inside the vector (gw not a multiple of VEC): element-wise statistics
                 const long long bp = (long long)b * HW + p;
-                const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
-                const float xh = (xv - mean) * rstd;
-                float dv = TI<T>::ld(dy, bp * C + c);
-                if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
-                sg += dv * xh; sb += dv;
+                const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+                const uint4 ud = *(const uint4*)(dy + bp * C + c);
+                TI<T>::unpack(ux, xh);
+                TI<T>::unpack(ud, dv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int ge = (c + e) / gw;
+                    const float mean = mean_rstd[((long long)b * 32 + ge) * 2], rstd = mean_rstd[((long long)b * 32 + ge) * 2 + 1];
+                    xh[e] = (xh[e] - mean) * rstd;
+                    if (silu) { const float pre = xh[e] * gamma[c + e] + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv[e] *= sgm * (1.0f + pre * (1.0f - sgm)); }
+                }
             }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sg[e] += dv[e] * xh[e]; sb[e] += dv[e]; }
         }
-        red[0][tid] = sg; red[1][tid] = sb;
     }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[(tid * VEC + e) * 2] = sg[e]; red[(tid * VEC + e) * 2 + 1] = sb[e]; }
     __syncthreads();
-    if (tid < gw) {
+    if (row == 0) {
+        for (int r = 1; r < rows; ++r) {
+            const int o = (r * cols_here + col) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sg[e] += red[(o + e) * 2]; sb[e] += red[(o + e) * 2 + 1]; }
+        }
+        float2* dst = partial + ((long long)b * nslab + slab) * C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dst[e] = make_float2(sg[e], sb[e]);
+    }
+}
+// grid (32 groups, B), one wave: lane = channel of the group (strided); slabs added in ascending order
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float2* __restrict__ partial, int nslab, int C, int HW, const float* __restrict__ gamma,
+                                                             float* __restrict__ dgam_part, float* __restrict__ dbet_part, float* __restrict__ mab) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int gw = C / 32, cg0 = g * gw;
+    float Sa = 0.f, Sb = 0.f;
+    for (int ci = lane; ci < gw; ci += 64) {
+        const int c = cg0 + ci;
         float sg = 0.f, sb = 0.f;
-        for (int r = 0; r < npr; ++r) { sg += red[0][r * gw + tid]; sb += red[1][r * gw + tid]; }
-        const int c = cg0 + tid;
+        for (int sl = 0; sl < nslab; ++sl) { const float2 v = partial[((long long)b * nslab + sl) * C + c]; sg += v.x; sb += v.y; }
         dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
-        const float gm = gamma[c];
-        red[0][tid] = gm * sb; red[1][tid] = gm * sg;      // own slot only (r = 0 was read by this thread alone)
+        Sa += gamma[c] * sb; Sb += gamma[c] * sg;
     }
-    __syncthreads();
-    if (tid == 0) {
-        float Sa = 0.f, Sb = 0.f;
-        for (int ci = 0; ci < gw; ++ci) { Sa += red[0][ci]; Sb += red[1][ci]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { Sa += __shfl_xor(Sa, o); Sb += __shfl_xor(Sb, o); }
+    if (lane == 0) {
         const float N = (float)gw * (float)HW;
-        msum[0] = Sa / N; msum[1] = Sb / N;
+        mab[((long long)b * 32 + g) * 2] = Sa / N; mab[((long long)b * 32 + g) * 2 + 1] = Sb / N;
     }
-    __syncthreads();
-    const float ma = msum[0], mb = msum[1];
-    const int total = HW * gw;
-    for (int id = tid; id < total; id += 256) {
-        const int p = id / gw, c = cg0 + (id - p * gw);
-        const long long bp = (long long)b * HW + p;
-        const float gm = gamma[c], bt = beta[c];
-        const float xv = c < C0 ? TI<T>::ld(x0, bp * xs0 + c) : TI<T>::ld(x1, bp * xs1 + (c - C0));
-        const float xh = (xv - mean) * rstd;
-        float dv = TI<T>::ld(dy, bp * C + c);
-        if (silu) { const float pre = xh * gm + bt; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv *= sgm * (1.0f + pre * (1.0f - sgm)); }
-        float d = rstd * (dv * gm - ma - xh * mb);
-        if (c < C0) { const long long o = bp * C0 + c; if (acc0) d += TI<T>::ld(dx0, o); TI<T>::st(dx0, o, d); }
-        else { const long long o = bp * C1 + (c - C0); if (acc1) d += TI<T>::ld(dx1, o); TI<T>::st(dx1, o, d); }
+}
+// elementwise over (image, pixel, 16-byte channel vector)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW, long long nvec,
+                                                           const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_rstd, const float* __restrict__ mab, int silu, T* __restrict__ dx0, int acc0,
+                                                           T* __restrict__ dx1, int acc1) {
+    constexpr int VEC = TI<T>::VEC;
+    const int cols = C / VEC, gw = C / 32, C1 = C - C0;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id % cols) * VEC;
+        const long long bp = id / cols;
+        const long long b = bp / HW;
+        const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+        const uint4 ud = *(const uint4*)(dy + bp * C + c);
+        float xh[VEC], dv[VEC], d[VEC];
+        TI<T>::unpack(ux, xh);
+        TI<T>::unpack(ud, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int g = (c + e) / gw;
+            const float mean = mean_rstd[(b * 32 + g) * 2], rstd = mean_rstd[(b * 32 + g) * 2 + 1];
+            const float ma = mab[(b * 32 + g) * 2], mb = mab[(b * 32 + g) * 2 + 1];
+            const float gm = gamma[c + e];
+            const float h = (xh[e] - mean) * rstd;
+            float v = dv[e];
+            if (silu) { const float pre = h * gm + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); v *= sgm * (1.0f + pre * (1.0f - sgm)); }
+            d[e] = rstd * (v * gm - ma - h * mb);
+        }
+        T* dst = c < C0 ? dx0 + bp * C0 + c : dx1 + bp * C1 + (c - C0);
+        if (c < C0 ? acc0 : acc1) {
+            float o[VEC];
+            TI<T>::unpack(*(const uint4*)dst, o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] += o[e];
+        }
+        *(uint4*)dst = TI<T>::pack(d);
     }
 }
 // dgamma[c] (+)= sum_b dgp[b][c], dbeta[c] (+)= sum_b dbp[b][c], both in image order
@@ -245,9 +327,15 @@ __global__ __launch_bounds__(256) void zero2_kernel(unsigned char* __restrict__ 
 }
 template <typename T>
 static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, const void* x1, int xs1, int C, int HW, const void* dy, const float* g, const float* bta,
-                         const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp) {
-    hipLaunchKernelGGL(gn_act_bwd_kernel<T>, dim3(32, B), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, (const T*)dy, g, bta, mr, silu, (T*)dx0, acc0,
-                       (T*)dx1, acc1, dgp, dbp);
+                         const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp, float2* partial, int nslab, float* mab) {
+    constexpr int VEC = TI<T>::VEC;
+    const int cols = C / VEC;
+    hipLaunchKernelGGL(gn_bwd_sums_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nslab, (const T*)dy, g,
+                       bta, mr, silu, partial);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, B), dim3(64), 0, s, partial, nslab, C, HW, g, dgp, dbp, mab);
+    const long long nvec = (long long)B * HW * cols;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(nblk(nvec, 256)), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nvec, (const T*)dy, g, bta, mr, mab,
+                       silu, (T*)dx0, acc0, (T*)dx1, acc1);
 }
 
 static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
@@ -255,11 +343,11 @@ static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
 // typed launch helpers ------------------------------------------------------------------------------------------------
 template <typename T>
 static void gather_t(hipStream_t s, const void* src, int xs, int c_off, int C, int B, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x, void* dst,
-                     int rows_per_img, int kp, int zero_rows_to = 0) {
-    // dst image stride is rows_per_img * kp; rows C .. zero_rows_to-1 of every image are zero-filled (the GEMM's padded M rows)
+                     int rows_per_img, int kp, int zero_rows_to = 0, int Bg = 1) {
+    // dst group stride is rows_per_img * Bg * kp; rows C .. zero_rows_to-1 of every image are zero-filled (the GEMM's padded M rows)
     const int crows = zero_rows_to > C ? zero_rows_to : C;
     hipLaunchKernelGGL(gather_t_kernel<T>, dim3((kp + 63) / 64, (crows + 63) / 64, B), dim3(256), 0, s, (const T*)src + c_off, xs, C, crows, H, W, Ho, Wo, stride, off_y,
-                       off_x, (T*)dst, (long long)rows_per_img * kp, kp);
+                       off_x, (T*)dst, (long long)rows_per_img * Bg * kp, kp, Bg);
 }
 #define BY_DTYPE(dtype, FN, ...) do { if ((dtype) == WDM_BF16) FN<__bf16>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
@@ -281,13 +369,13 @@ template <typename T> static void l_pad_channels(hipStream_t s, const void* x, i
     hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)x, C, Cp, (T*)y, total);
 }
 // needs a scratch buffer of groups * nchunks * C floats
-static inline int colsum_chunks(long long rows_per_group) { long long n = (rows_per_group + 255) / 256; return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n)); }
+static inline int colsum_chunks(long long rows_per_group) { long long n = (rows_per_group + 255) / 256; return (int)(n < 1 ? 1 : (n > 256 ? 256 : n)); }
 template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc, int out_ld,
                                            float* scratch) {
     const int nchunks = colsum_chunks(rows_per_group);
     const int chunk_rows = (int)((rows_per_group + nchunks - 1) / nchunks);
     hipLaunchKernelGGL(colsum_part_kernel<T>, dim3((C + 63) / 64, groups, nchunks), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, chunk_rows, nchunks, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, s, scratch, C, nchunks, groups, out, out_ld ? out_ld : C, acc);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, s, scratch, C, nchunks, groups, out, out_ld ? out_ld : C, acc);
 }
 
 // ---- dgrad: dx (+)= conv^T(dy).  (H, W) is the forward INPUT map; dy is dense NHWC [B][Ho][Wo][cout]; dx dense [B][H][W][cin].
@@ -376,6 +464,17 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     }
     (void)up1; (void)t_up1;
     const bool shifted = (mode == MODE_S1 || mode == MODE_UPS);
+    // Images are contracted in groups of Bg (K = Bg x pixels per GEMM row): one fp32 partial per GROUP instead of per image.  Bg is the
+    // largest divisor of B that still leaves ~512 workgroups per launch (small layers need the split over images for parallelism).
+    int Bg = 1;
+    {
+        const long long wgs = (long long)(shifted ? 9 : 1) * ((rows_g + 127) / 128) * ((cin + 127) / 128);
+        const long long s_min = (512 + wgs - 1) / wgs;
+        for (int d = 1; d <= c.B; ++d)
+            if (c.B % d == 0 && c.B / d >= s_min) Bg = d;
+        if (const char* e = getenv("WDM_WGRAD_BG")) { const int v = atoi(e); if (v >= 1 && c.B % v == 0) Bg = v; }
+    }
+    const int S = c.B / Bg;
     int rc = WDM_OK;
     if (shifted) {
         // 3x3 stride 1: ONE transposed image per dx column on a grid of (H + 2) rows x Wq columns (Wq = W rounded up to 8, so that a
@@ -387,33 +486,35 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         const size_t a_elems = (size_t)c.B * cin * kq;
         void* dyT = c.ar->alloc((size_t)c.B * rows_g * kq * es);
         char* aT3 = (char*)c.ar->alloc((3 * a_elems + 2 * (size_t)Wq) * es);
-        float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
+        float* part = (float*)c.ar->alloc((size_t)kk * S * rows_g * cin * sizeof(float));
         if (!dyT || !aT3 || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
         if (!c.dry) {
             hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c.s, (unsigned char*)aT3, (long long)((size_t)Wq * es),
                                (unsigned char*)aT3 + ((size_t)Wq + 3 * a_elems) * es, (long long)((size_t)Wq * es));
-            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq, rows_g);
+            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq, rows_g, Bg);
             for (int dx = 0; dx < 3; ++dx) {
                 char* dst = aT3 + ((size_t)Wq + dx * a_elems) * es;
-                BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq);
-                if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst + (size_t)s0->C * kq * es, cin, kq);
+                BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq, 0, Bg);
+                if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst + (size_t)s0->C * Bg * kq * es, cin, kq, 0, Bg);
             }
-            {   // the nine taps as ONE batched GEMM: image i = tap * B + b reads dyT[b] and aT_{tap % 3}[b] shifted by (tap / 3 - 1) rows
+            {   // the nine taps as ONE batched GEMM: "image" i = tap * S + g reads dyT[g] and aT_{tap % 3}[g] shifted by (tap / 3 - 1) grid rows;
+                // a row is the concatenation of the group's Bg images (a shift that leaves an image's segment meets that image's zero border in dyT)
+                const int kg = Bg * kq;
                 ConvArgs a{};
-                a.x0 = dyT; a.C0 = kq; a.xs0 = kq; a.C1 = 0;
-                a.B = 9 * c.B; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
-                a.Cin = kq; a.Cout = cin;
+                a.x0 = dyT; a.C0 = kg; a.xs0 = kg; a.C1 = 0;
+                a.B = 9 * S; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
+                a.Cin = kg; a.Cout = cin;
                 a.w = aT3 + (size_t)Wq * es;
-                a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kq; a.w_row_stride = kq; a.w_rows = cin;
-                a.img_mod = c.B; a.w_tx_stride = (long long)a_elems; a.w_ty_stride = Wq;
-                a.w_bytes = (unsigned)((size_t)cin * kq * es);
+                a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kg; a.w_row_stride = kg; a.w_rows = cin;
+                a.img_mod = S; a.w_tx_stride = (long long)a_elems; a.w_ty_stride = Wq;
+                a.w_bytes = (unsigned)((size_t)cin * kg * es);
                 a.alpha = 1.f;
                 a.y = part; a.y_mode = Y_NHWC_F32; a.y_s = cin;
                 rc = launch_conv(a, MODE_P1, c.dtype, c.s);
             }
             if (rc == WDM_OK) {
                 const long long total = (long long)kk * cout * cin;
-                hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, c.B, rows_g, cout, cin, dw, accumulate ? 1 : 0);
+                hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, S, rows_g, cout, cin, dw, accumulate ? 1 : 0);
                 WDM_HIP(hipGetLastError());
             }
         }
@@ -423,29 +524,30 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     }
     void* dyT = c.ar->alloc((size_t)c.B * rows_g * kp * es);
     void* aT = c.ar->alloc((size_t)c.B * cin * kp * es);
-    float* part = (float*)c.ar->alloc((size_t)kk * c.B * rows_g * cin * sizeof(float));
+    float* part = (float*)c.ar->alloc((size_t)kk * S * rows_g * cin * sizeof(float));
     if (!dyT || !aT || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
     if (!c.dry) {
-        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp, rows_g);
+        const int kg = Bg * kp;
+        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp, rows_g, Bg);
         const int stride = mode == MODE_S2 ? 2 : 1;
         for (int tap = 0; tap < kk && rc == WDM_OK; ++tap) {
             const int ty = tap / k, tx = tap % k;
             const int oy = mode == MODE_P1 ? 0 : ty, ox = mode == MODE_P1 ? 0 : tx;      // Downsample: pad(0,1,0,1), stride 2
-            BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Ho, Wo, stride, oy, ox, aT, cin, kp);
-            if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Ho, Wo, stride, oy, ox, (char*)aT + (size_t)s0->C * kp * es, cin, kp);
+            BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Ho, Wo, stride, oy, ox, aT, cin, kp, 0, Bg);
+            if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Ho, Wo, stride, oy, ox, (char*)aT + (size_t)s0->C * kg * es, cin, kp, 0, Bg);
             ConvArgs a{};
-            a.x0 = dyT; a.C0 = kp; a.xs0 = kp; a.C1 = 0;
-            a.B = c.B; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
-            a.Cin = kp; a.Cout = cin;
-            a.w = aT; a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kp; a.w_row_stride = kp; a.w_rows = cin;
-            a.w_bytes = (unsigned)((size_t)cin * kp * es);
+            a.x0 = dyT; a.C0 = kg; a.xs0 = kg; a.C1 = 0;
+            a.B = S; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
+            a.Cin = kg; a.Cout = cin;
+            a.w = aT; a.w_tap_stride = 0; a.w_img_stride = (long long)cin * kg; a.w_row_stride = kg; a.w_rows = cin;
+            a.w_bytes = (unsigned)((size_t)cin * kg * es);
             a.alpha = 1.f;
-            a.y = part + (size_t)tap * c.B * rows_g * cin; a.y_mode = Y_NHWC_F32; a.y_s = cin;
+            a.y = part + (size_t)tap * S * rows_g * cin; a.y_mode = Y_NHWC_F32; a.y_s = cin;
             rc = launch_conv(a, MODE_P1, c.dtype, c.s);
         }
         if (rc == WDM_OK) {
             const long long total = (long long)kk * cout * cin;
-            hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, c.B, rows_g, cout, cin, dw, accumulate ? 1 : 0);
+            hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, kk, S, rows_g, cout, cin, dw, accumulate ? 1 : 0);
             WDM_HIP(hipGetLastError());
         }
     }
@@ -472,12 +574,17 @@ int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, 
 int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
                     bool acc1, float* dgamma, float* dbeta, bool acc_param) {
     const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
-    if (C % 32 || C / 32 > 256) WDM_FAIL(WDM_EINVAL, "GroupNorm backward: %d channels unsupported (multiple of 32, <= 8192)", C);
-    float* part = (float*)c.ar->alloc((size_t)2 * c.B * C * sizeof(float));
+    const int vec = c.dtype == WDM_BF16 ? 8 : 4;
+    if (C % 32 || x0.C % vec || C % vec) WDM_FAIL(WDM_EINVAL, "GroupNorm backward: %d (+%d) channels unsupported", x0.C, C - x0.C);
+    const int nslab = gn_default_nslab(HW);
+    // per-image dgamma / dbeta [2][B][C], slab partials [B][nslab][C] x 2, group means [B][32] x 2
+    float* part = (float*)c.ar->alloc(((size_t)2 * c.B * C + (size_t)2 * c.B * nslab * C + (size_t)2 * c.B * 32) * sizeof(float));
     if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm backward)");
     if (!c.dry) {
+        float* slabs = part + (size_t)2 * c.B * C;
+        float* mab = slabs + (size_t)2 * c.B * nslab * C;
         BY_DTYPE(c.dtype, l_gn_act_bwd, c.s, c.B, x0.p, x0.xs, x0.C, x1 ? x1->p : x0.p, x1 ? x1->xs : 0, C, HW, dy.p, nw.g, nw.b, mean_rstd, silu, dx0, acc0 ? 1 : 0,
-                 x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C);
+                 x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C, (float2*)slabs, nslab, mab);
         hipLaunchKernelGGL(sum_images2_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, c.s, part, part + (size_t)c.B * C, c.B, C, dgamma, dbeta, acc_param ? 1 : 0);
         WDM_HIP(hipGetLastError());
     }
@@ -488,7 +595,7 @@ int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, con
 // dst[b][c][n] = src[b][n][c]  (tokens n = 0..N-1, dense rows of C): the attention backward's operand transposes
 int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst) {
     if (c.dry) return WDM_OK;
-    BY_DTYPE(c.dtype, gather_t, c.s, src, Cc, 0, Cc, c.B, 1, N, 1, N, 1, 0, 0, dst, Cc, N);
+    BY_DTYPE(c.dtype, gather_t, c.s, src, Cc, 0, Cc, c.B, 1, N, 1, N, 1, 0, 0, dst, Cc, N, 0, 1);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
