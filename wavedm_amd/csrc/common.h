@@ -168,7 +168,9 @@ void free_tens(Ctx& c, Tens& t);
 
 // ---- training step: backward primitives (train.hip) ---------------------------------------------------------------
 int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate);
-int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate);
+// db / dtemb (optional): bias gradient and per-image column sums of dy (rows of length dtemb_ld), taken from the same pass that transposes dy
+int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate, float* db = nullptr, float* dtemb = nullptr,
+               int dtemb_ld = 0);
 int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, int out_ld = 0);
 int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, const float* mean_rstd, const Tens& dy, int silu, void* dx0, bool acc0, void* dx1,
                     bool acc1, float* dgamma, float* dbeta, bool acc_param);

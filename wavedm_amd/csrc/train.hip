@@ -16,16 +16,22 @@ namespace wdm {
 static inline int nblk(long long n, int bs) { long long g = (n + bs - 1) / bs; return (int)(g > 16384 ? 16384 : g); }
 
 // dst[b][c][k] (row length kp, k = oy*Wo + ox; image stride dst_img elements) = src[b][stride*oy + off_y][stride*ox + off_x][c]
-// (0 outside the map / past Ho*Wo); rows C <= c < Crows are written as zeros.  A 64-channel x 64-position tile per workgroup goes
-// through LDS, so the reads run along the channels of a pixel and the writes along the positions of a channel: both coalesced.
+// (0 outside the map / past Ho*Wo), src = the channel concat [src0 (C0 channels) | src1]; rows C <= c < Crows are written as zeros.
+// A 64-channel x 64-position tile per workgroup goes through LDS, so the reads run along the channels of a pixel and the writes along the
+// positions of a channel: both coalesced.
 // Bg > 1: the images are laid out in groups of Bg along the row -- dst[b / Bg][c][b % Bg][k], dst_img = elements per GROUP -- so that a GEMM
-// over a row contracts the pixels of Bg images at once (conv_wgrad).
+// over a row contracts the pixels of Bg images at once (conv_wgrad).  ndx = 3: blockIdx.z also runs over three copies shifted by
+// off_x - 1, off_x, off_x + 1 columns, dst_dx elements apart (the dx taps of a 3x3 wgrad).
 template <typename T>
-__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src, int xs, int C, int Crows, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x,
-                                                       T* __restrict__ dst, long long dst_img, int kp, int Bg) {
+__global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src0, int xs0, int C0, const T* __restrict__ src1, int xs1, int C, int Crows, int H, int W,
+                                                       int Ho, int Wo, int stride, int off_y, int off_x, T* __restrict__ dst, long long dst_img, int kp, int Bg, int B,
+                                                       long long dst_dx, float* __restrict__ csum) {
     __shared__ float tile[64][65];
+    __shared__ float cred[4][64];
     const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const long long b = blockIdx.z;
+    const int dxi = blockIdx.z / B;
+    const long long b = blockIdx.z - dxi * B;
+    if (gridDim.z > (unsigned)B) { off_x += dxi - 1; dst += dxi * dst_dx; }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     if (c0 < C) {
         const int c = c0 + tx;
@@ -35,12 +41,22 @@ __global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src
             if (c < C && k < Ho * Wo) {
                 const int oy = k / Wo, ox = k - oy * Wo;
                 const int y = stride * oy + off_y, x = stride * ox + off_x;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = TI<T>::ld(src, ((b * H + y) * W + x) * xs + c);
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                    const long long px = (b * H + y) * W + x;
+                    v = c < C0 ? TI<T>::ld(src0, px * xs0 + c) : TI<T>::ld(src1, px * xs1 + (c - C0));
+                }
             }
             tile[j][tx] = v;
         }
     }
     __syncthreads();
+    if (csum != nullptr && c0 < C) {                  // column sums of this tile: csum[b][k tile][c] (bias / temb gradients, summed later in tile order)
+        float a4 = 0.f;
+        for (int j = ty; j < 64; j += 4) a4 += tile[j][tx];
+        cred[ty][tx] = a4;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) csum[((long long)b * gridDim.x + blockIdx.x) * C + c0 + tx] = (cred[0][tx] + cred[1][tx]) + (cred[2][tx] + cred[3][tx]);
+    }
     const int k = k0 + tx;
     if (k >= kp) return;
     for (int j = ty; j < 64; j += 4) {
@@ -80,14 +96,14 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
     if (sl == 0 && c < C) part[((long long)g * nchunks + ch) * C + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 // 64 channels x 4 chunk slices per workgroup; the four slice sums are added in a fixed order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int C, int nchunks, int groups, float* __restrict__ out, int out_ld,
-                                                           int accumulate) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int part_ld, int C, int nchunks, int groups, float* __restrict__ out,
+                                                           int out_ld, int accumulate) {
     __shared__ float red[256];
     const int g = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     float s = 0.f;
     if (c < C)
-        for (int k = sl; k < nchunks; k += 4) s += part[((long long)g * nchunks + k) * C + c];
+        for (int k = sl; k < nchunks; k += 4) s += part[((long long)g * nchunks + k) * part_ld + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0 && c < C) {
@@ -249,24 +265,33 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ 
         for (int e = 0; e < VEC; ++e) dst[e] = make_float2(sg[e], sb[e]);
     }
 }
-// grid (32 groups, B), one wave: lane = channel of the group (strided); slabs added in ascending order
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float2* __restrict__ partial, int nslab, int C, int HW, const float* __restrict__ gamma,
-                                                             float* __restrict__ dgam_part, float* __restrict__ dbet_part, float* __restrict__ mab) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// grid (32 groups), 256 threads: every (image, channel of the group) pair adds its slabs in ascending order; then per image the group means
+// (mab) and per channel the batch sums dgamma / dbeta (images in ascending order), all inside the workgroup
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __restrict__ partial, int nslab, int B, int C, int HW, const float* __restrict__ gamma,
+                                                             float* __restrict__ dgam_part, float* __restrict__ dbet_part, float* __restrict__ mab,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int g = blockIdx.x, tid = threadIdx.x;
     const int gw = C / 32, cg0 = g * gw;
-    float Sa = 0.f, Sb = 0.f;
-    for (int ci = lane; ci < gw; ci += 64) {
-        const int c = cg0 + ci;
+    for (int i = tid; i < B * gw; i += 256) {
+        const int b = i / gw, c = cg0 + (i - b * gw);
         float sg = 0.f, sb = 0.f;
         for (int sl = 0; sl < nslab; ++sl) { const float2 v = partial[((long long)b * nslab + sl) * C + c]; sg += v.x; sb += v.y; }
         dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
-        Sa += gamma[c] * sb; Sb += gamma[c] * sg;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { Sa += __shfl_xor(Sa, o); Sb += __shfl_xor(Sb, o); }
-    if (lane == 0) {
-        const float N = (float)gw * (float)HW;
+    __syncthreads();                                   // the per-image sums were written by this workgroup
+    const float N = (float)gw * (float)HW;
+    for (int b = tid; b < B; b += 256) {
+        float Sa = 0.f, Sb = 0.f;
+        for (int ci = 0; ci < gw; ++ci) { const int c = cg0 + ci; Sa += gamma[c] * dbet_part[(long long)b * C + c]; Sb += gamma[c] * dgam_part[(long long)b * C + c]; }
         mab[((long long)b * 32 + g) * 2] = Sa / N; mab[((long long)b * 32 + g) * 2 + 1] = Sb / N;
+    }
+    for (int i = tid; i < 2 * gw; i += 256) {
+        const int c = cg0 + (i < gw ? i : i - gw);
+        const float* src = i < gw ? dgam_part : dbet_part;
+        float* out = i < gw ? dgamma : dbeta;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += src[(long long)b * C + c];
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
 // elementwise over (image, pixel, 16-byte channel vector)
@@ -307,18 +332,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         *(uint4*)dst = TI<T>::pack(d);
     }
 }
-// dgamma[c] (+)= sum_b dgp[b][c], dbeta[c] (+)= sum_b dbp[b][c], both in image order
-__global__ __launch_bounds__(256) void sum_images2_kernel(const float* __restrict__ dgp, const float* __restrict__ dbp, int B, int C, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int accumulate) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 2 * C) return;
-    const int c = id < C ? id : id - C;
-    const float* src = id < C ? dgp : dbp;
-    float* out = id < C ? dgamma : dbeta;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += src[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
-}
 // zero two small ranges of 16-bit / 32-bit elements (the margins around the shifted wgrad operand) in one launch
 __global__ __launch_bounds__(256) void zero2_kernel(unsigned char* __restrict__ p0, long long n0, unsigned char* __restrict__ p1, long long n1) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += (long long)gridDim.x * blockDim.x) {
@@ -327,12 +340,13 @@ __global__ __launch_bounds__(256) void zero2_kernel(unsigned char* __restrict__ 
 }
 template <typename T>
 static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, const void* x1, int xs1, int C, int HW, const void* dy, const float* g, const float* bta,
-                         const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp, float2* partial, int nslab, float* mab) {
+                         const float* mr, int silu, void* dx0, int acc0, void* dx1, int acc1, float* dgp, float* dbp, float2* partial, int nslab, float* mab,
+                         float* dgamma, float* dbeta, int acc_param) {
     constexpr int VEC = TI<T>::VEC;
     const int cols = C / VEC;
     hipLaunchKernelGGL(gn_bwd_sums_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nslab, (const T*)dy, g,
                        bta, mr, silu, partial);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, B), dim3(64), 0, s, partial, nslab, C, HW, g, dgp, dbp, mab);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32), dim3(256), 0, s, partial, nslab, B, C, HW, g, dgp, dbp, mab, dgamma, dbeta, acc_param);
     const long long nvec = (long long)B * HW * cols;
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(nblk(nvec, 256)), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nvec, (const T*)dy, g, bta, mr, mab,
                        silu, (T*)dx0, acc0, (T*)dx1, acc1);
@@ -342,12 +356,13 @@ static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
 
 // typed launch helpers ------------------------------------------------------------------------------------------------
 template <typename T>
-static void gather_t(hipStream_t s, const void* src, int xs, int c_off, int C, int B, int H, int W, int Ho, int Wo, int stride, int off_y, int off_x, void* dst,
-                     int rows_per_img, int kp, int zero_rows_to = 0, int Bg = 1) {
+static void gather_t(hipStream_t s, const void* src0, int xs0, int C0, const void* src1, int xs1, int C1, int B, int H, int W, int Ho, int Wo, int stride, int off_y,
+                     int off_x, void* dst, int rows_per_img, int kp, int zero_rows_to, int Bg, int ndx, long long dst_dx, float* csum = nullptr) {
     // dst group stride is rows_per_img * Bg * kp; rows C .. zero_rows_to-1 of every image are zero-filled (the GEMM's padded M rows)
+    const int C = C0 + C1;
     const int crows = zero_rows_to > C ? zero_rows_to : C;
-    hipLaunchKernelGGL(gather_t_kernel<T>, dim3((kp + 63) / 64, (crows + 63) / 64, B), dim3(256), 0, s, (const T*)src + c_off, xs, C, crows, H, W, Ho, Wo, stride, off_y,
-                       off_x, (T*)dst, (long long)rows_per_img * Bg * kp, kp, Bg);
+    hipLaunchKernelGGL(gather_t_kernel<T>, dim3((kp + 63) / 64, (crows + 63) / 64, B * ndx), dim3(256), 0, s, (const T*)src0, xs0, C0, (const T*)(src1 ? src1 : src0), xs1, C,
+                       crows, H, W, Ho, Wo, stride, off_y, off_x, (T*)dst, (long long)rows_per_img * Bg * kp, kp, Bg, B, dst_dx, csum);
 }
 #define BY_DTYPE(dtype, FN, ...) do { if ((dtype) == WDM_BF16) FN<__bf16>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
@@ -375,7 +390,7 @@ template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs,
     const int nchunks = colsum_chunks(rows_per_group);
     const int chunk_rows = (int)((rows_per_group + nchunks - 1) / nchunks);
     hipLaunchKernelGGL(colsum_part_kernel<T>, dim3((C + 63) / 64, groups, nchunks), dim3(256), 0, s, (const T*)x, xs, C, rows_per_group, chunk_rows, nchunks, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, s, scratch, C, nchunks, groups, out, out_ld ? out_ld : C, acc);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, s, scratch, C, C, nchunks, groups, out, out_ld ? out_ld : C, acc);
 }
 
 // ---- dgrad: dx (+)= conv^T(dy).  (H, W) is the forward INPUT map; dy is dense NHWC [B][Ho][Wo][cout]; dx dense [B][H][W][cin].
@@ -436,9 +451,27 @@ int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const T
     return rc;
 }
 
+// tile column sums csum[B][nkt][cout] (from the dy gather) -> per-image sums (into dtemb when asked for, else a scratch) -> bias gradient; frees csum
+static int finish_colsums(Ctx& c, float* csum, int nkt, int cout, float* db, float* dtemb, int dtemb_ld) {
+    if (!csum) return WDM_OK;
+    float* per_img = dtemb;
+    int ld = dtemb_ld;
+    if (!per_img) {
+        per_img = (float*)c.ar->alloc((size_t)c.B * cout * sizeof(float));
+        if (!per_img) WDM_FAIL(WDM_ENOMEM, "workspace too small (bias gradient)");
+        ld = cout;
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64, c.B), dim3(256), 0, c.s, csum, cout, cout, nkt, c.B, per_img, ld, 0);
+    if (db) hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64, 1), dim3(256), 0, c.s, per_img, ld, cout, c.B, 1, db, cout, 0);
+    WDM_HIP(hipGetLastError());
+    if (!dtemb) c.ar->free(per_img);
+    c.ar->free(csum);
+    return WDM_OK;
+}
+
 // ---- wgrad: dw[co][ci][tap] (OIHW f32) (+)= sum_pixels dy[p][co] * x[p + tap][ci];  x = [x0 | x1] (the forward input; for MODE_UPS the
 // low-resolution map, upsampled here), dy dense [B][Ho][Wo][cout]
-int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate) {
+int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate, float* db, float* dtemb, int dtemb_ld) {
     const int cin = x0.C + (x1 ? x1->C : 0);
     const int k = mode == MODE_P1 ? 1 : 3, kk = k * k;
     const size_t es = dsize(c.dtype);
@@ -491,12 +524,14 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         if (!c.dry) {
             hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c.s, (unsigned char*)aT3, (long long)((size_t)Wq * es),
                                (unsigned char*)aT3 + ((size_t)Wq + 3 * a_elems) * es, (long long)((size_t)Wq * es));
-            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq, rows_g, Bg);
-            for (int dx = 0; dx < 3; ++dx) {
-                char* dst = aT3 + ((size_t)Wq + dx * a_elems) * es;
-                BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst, cin, kq, 0, Bg);
-                if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Hq, Wq, 1, -1, dx - 1, dst + (size_t)s0->C * Bg * kq * es, cin, kq, 0, Bg);
-            }
+            const int nkt = (kq + 63) / 64;
+            float* csum = (db || dtemb) ? (float*)c.ar->alloc((size_t)c.B * nkt * cout * sizeof(float)) : nullptr;
+            if ((db || dtemb) && !csum) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad column sums)");
+            BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, cout, nullptr, 0, 0, c.B, Ho, Wo, Hq, Wq, 1, -1, 0, dyT, rows_g, kq, rows_g, Bg, 1, 0, csum);
+            WDM_TRY(finish_colsums(c, csum, nkt, cout, db, dtemb, dtemb_ld));
+            // the three dx-shifted copies of [x0 | x1] in one launch
+            BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, s0->C, s1 ? s1->p : nullptr, s1 ? s1->xs : 0, s1 ? s1->C : 0, c.B, H, W, Hq, Wq, 1, -1, 0,
+                     aT3 + (size_t)Wq * es, cin, kq, 0, Bg, 3, (long long)a_elems);
             {   // the nine taps as ONE batched GEMM: "image" i = tap * S + g reads dyT[g] and aT_{tap % 3}[g] shifted by (tap / 3 - 1) grid rows;
                 // a row is the concatenation of the group's Bg images (a shift that leaves an image's segment meets that image's zero border in dyT)
                 const int kg = Bg * kq;
@@ -528,13 +563,17 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     if (!dyT || !aT || !part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad)");
     if (!c.dry) {
         const int kg = Bg * kp;
-        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, 0, cout, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp, rows_g, Bg);
+        const int nkt = (kp + 63) / 64;
+        float* csum = (db || dtemb) ? (float*)c.ar->alloc((size_t)c.B * nkt * cout * sizeof(float)) : nullptr;
+        if ((db || dtemb) && !csum) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad column sums)");
+        BY_DTYPE(c.dtype, gather_t, c.s, dy.p, dy.xs, cout, nullptr, 0, 0, c.B, Ho, Wo, Ho, Wo, 1, 0, 0, dyT, rows_g, kp, rows_g, Bg, 1, 0, csum);
+        WDM_TRY(finish_colsums(c, csum, nkt, cout, db, dtemb, dtemb_ld));
         const int stride = mode == MODE_S2 ? 2 : 1;
         for (int tap = 0; tap < kk && rc == WDM_OK; ++tap) {
             const int ty = tap / k, tx = tap % k;
             const int oy = mode == MODE_P1 ? 0 : ty, ox = mode == MODE_P1 ? 0 : tx;      // Downsample: pad(0,1,0,1), stride 2
-            BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, 0, s0->C, c.B, H, W, Ho, Wo, stride, oy, ox, aT, cin, kp, 0, Bg);
-            if (s1) BY_DTYPE(c.dtype, gather_t, c.s, s1->p, s1->xs, 0, s1->C, c.B, H, W, Ho, Wo, stride, oy, ox, (char*)aT + (size_t)s0->C * kg * es, cin, kp, 0, Bg);
+            BY_DTYPE(c.dtype, gather_t, c.s, s0->p, s0->xs, s0->C, s1 ? s1->p : nullptr, s1 ? s1->xs : 0, s1 ? s1->C : 0, c.B, H, W, Ho, Wo, stride, oy, ox, aT, cin, kp,
+                     0, Bg, 1, 0);
             ConvArgs a{};
             a.x0 = dyT; a.C0 = kg; a.xs0 = kg; a.C1 = 0;
             a.B = S; a.Hin = a.Hout = Hg; a.Win = a.Wout = Wg;
@@ -576,7 +615,12 @@ int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, con
     const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
     const int vec = c.dtype == WDM_BF16 ? 8 : 4;
     if (C % 32 || x0.C % vec || C % vec) WDM_FAIL(WDM_EINVAL, "GroupNorm backward: %d (+%d) channels unsupported", x0.C, C - x0.C);
-    const int nslab = gn_default_nslab(HW);
+    // slabs: at most ~4 pixel iterations per thread (8 x 8 maps with hundreds of channels would otherwise run B long-latency workgroups)
+    int nslab;
+    {
+        const int cols = C / vec, rows = std::max(1, 256 / std::min(cols, 256));
+        nslab = std::min(256, std::max(1, HW / (4 * rows)));
+    }
     // per-image dgamma / dbeta [2][B][C], slab partials [B][nslab][C] x 2, group means [B][32] x 2
     float* part = (float*)c.ar->alloc(((size_t)2 * c.B * C + (size_t)2 * c.B * nslab * C + (size_t)2 * c.B * 32) * sizeof(float));
     if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm backward)");
@@ -584,8 +628,7 @@ int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, con
         float* slabs = part + (size_t)2 * c.B * C;
         float* mab = slabs + (size_t)2 * c.B * nslab * C;
         BY_DTYPE(c.dtype, l_gn_act_bwd, c.s, c.B, x0.p, x0.xs, x0.C, x1 ? x1->p : x0.p, x1 ? x1->xs : 0, C, HW, dy.p, nw.g, nw.b, mean_rstd, silu, dx0, acc0 ? 1 : 0,
-                 x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C, (float2*)slabs, nslab, mab);
-        hipLaunchKernelGGL(sum_images2_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, c.s, part, part + (size_t)c.B * C, c.B, C, dgamma, dbeta, acc_param ? 1 : 0);
+                 x1 ? dx1 : dx0, acc1 ? 1 : 0, part, part + (size_t)c.B * C, (float2*)slabs, nslab, mab, dgamma, dbeta, acc_param ? 1 : 0);
         WDM_HIP(hipGetLastError());
     }
     c.ar->free(part);
@@ -595,7 +638,7 @@ int gn_act_backward(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, con
 // dst[b][c][n] = src[b][n][c]  (tokens n = 0..N-1, dense rows of C): the attention backward's operand transposes
 int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst) {
     if (c.dry) return WDM_OK;
-    BY_DTYPE(c.dtype, gather_t, c.s, src, Cc, 0, Cc, c.B, 1, N, 1, N, 1, 0, 0, dst, Cc, N, 0, 1);
+    BY_DTYPE(c.dtype, gather_t, c.s, src, Cc, Cc, nullptr, 0, 0, c.B, 1, N, 1, N, 1, 0, 0, dst, Cc, N, 0, 1, 1, 0);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -627,8 +670,7 @@ extern "C" int wdm_conv_backward(wdm_handle* h, const float* w, int cin, int cou
         WDM_TRY(conv_dgrad(c, mode, w, cin, cout, tdy, H, W, tdx, false));
         WDM_TRY(k_nhwc_to_nchw(tdx, dx, B, cin, H, W, dtype, c.s));
     }
-    WDM_TRY(conv_wgrad(c, mode, tx, nullptr, tdy, cout, dw, false));
-    if (db) WDM_TRY(colsum(c, tdy, db, false, false));
+    WDM_TRY(conv_wgrad(c, mode, tx, nullptr, tdy, cout, dw, false, db));
     return WDM_OK;
 }
 

@@ -316,9 +316,8 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
         Ctx& cx = *c;
         if (!o->g) WDM_FAIL(WDM_ESTATE, "backward: conv output without gradient");
         const Tens dy = gtens(o);
-        WDM_TRY(colsum(cx, dy, G + pp.b, false, false));
-        WDM_TRY(conv_wgrad(cx, mode, x0->t, x1 ? &x1->t : nullptr, dy, pp.cout, G + pp.w, false));
-        if (temb_row >= 0) WDM_TRY(colsum(cx, dy, d_temb_all + temb_row, true, false, temb_rows));
+        // weight, bias and (ResnetBlock conv1) per-image temb gradients: the column sums come out of the pass that transposes dy
+        WDM_TRY(conv_wgrad(cx, mode, x0->t, x1 ? &x1->t : nullptr, dy, pp.cout, G + pp.w, false, G + pp.b, temb_row >= 0 ? d_temb_all + temb_row : nullptr, temb_rows));
         const long long n_out = (long long)cx.B * dy.H * dy.W * dy.C;
         if (res && res->needs_grad) { bool first; WDM_TRY(grad_buf(res, &first)); BYT(cx.dtype, l_add_into, cx.s, res->g, o->g, n_out, first ? 0 : 1); }
         if (x0->needs_grad) {
