@@ -167,7 +167,11 @@ int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);
 void free_tens(Ctx& c, Tens& t);
 
 // ---- training step: backward primitives (train.hip) ---------------------------------------------------------------
-int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate);
+// wd_prepacked: the transposed / mirrored weights already packed by k_pack_conv_both (else packed here from w_oihw)
+int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate, const void* wd_prepacked = nullptr);
+size_t conv_dgrad_packed_bytes(int cin, int cout, int k, int dtype);
+// forward layout [tap][rows_total][cin] AND dgrad layout [taps-1-tap][conv_rows_pad(cin)][cout padded] from one pass over the OIHW weights
+int k_pack_conv_both(const float* w_oihw, int cout, int cin, int k, void* dst_fwd, int rows_total, void* dst_dgrad, int dtype, hipStream_t s);
 // db / dtemb (optional): bias gradient and per-image column sums of dy (rows of length dtemb_ld), taken from the same pass that transposes dy
 int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate, float* db = nullptr, float* dtemb = nullptr,
                int dtemb_ld = 0);

@@ -375,6 +375,29 @@ template <typename T> static void l_upsample2(hipStream_t s, const void* x, int 
 template <typename T> static void l_sumpool2(hipStream_t s, const void* dy, int C, int h, int w, void* dx, int acc, long long total) {
     hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)dy, C, h, w, (T*)dx, acc, total);
 }
+// one pass over OIHW: forward layout dstf[tap][rows_total][cin] (rows >= cout zero) and dgrad layout dstd[KK-1-tap][rows_d][kpad] (transposed)
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dstf, int rows_total, T* __restrict__ dstd,
+                                                        int rows_d, int kpad) {
+    constexpr int ROW = 32 * KK;
+    __shared__ float sm[32][ROW + 1];
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int nci = min(32, cin - ci0);
+    for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+        const int co = co0 + r;
+        for (int e = threadIdx.x & 31; e < ROW; e += 32)
+            sm[r][e] = (co < cout && e < nci * KK) ? w[((long long)co * cin + ci0) * KK + e] : 0.f;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 31;
+    for (int tp = 0; tp < KK; ++tp)
+        for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+            // forward: row co0 + r, 32 consecutive input channels
+            if (co0 + r < rows_total && ci0 + l < cin) TI<T>::st(dstf, ((long long)tp * rows_total + co0 + r) * cin + ci0 + l, sm[r][l * KK + tp]);
+            // dgrad: row ci0 + r, 32 consecutive output channels, taps mirrored
+            if (ci0 + r < rows_d && co0 + l < kpad) TI<T>::st(dstd, ((long long)tp * rows_d + ci0 + r) * kpad + co0 + l, sm[l][r * KK + (KK - 1 - tp)]);
+        }
+}
 template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, int cout, int cin, int kk, void* dst, int rows, int kpad) {
     const dim3 grid((kpad + 31) / 32, (rows + 31) / 32);
     if (kk == 9) hipLaunchKernelGGL((pack_dgrad_kernel<T, 9>), grid, dim3(256), 0, s, w, cout, cin, (T*)dst, rows, kpad);
@@ -394,14 +417,30 @@ template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs,
 }
 
 // ---- dgrad: dx (+)= conv^T(dy).  (H, W) is the forward INPUT map; dy is dense NHWC [B][Ho][Wo][cout]; dx dense [B][H][W][cin].
-int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate) {
+size_t conv_dgrad_packed_bytes(int cin, int cout, int k, int dtype) {
+    return (size_t)k * k * conv_rows_pad(cin) * align_up((size_t)cout, kalign(dtype)) * dsize(dtype);
+}
+int k_pack_conv_both(const float* w_oihw, int cout, int cin, int k, void* dst_fwd, int rows_total, void* dst_dgrad, int dtype, hipStream_t s) {
+    const int rows_d = conv_rows_pad(cin), kpad = (int)align_up((size_t)cout, kalign(dtype));
+    const dim3 grid((std::max(rows_total, kpad) + 31) / 32, (std::max(cin, rows_d) + 31) / 32);
+    if (dtype == WDM_BF16) {
+        if (k == 3) hipLaunchKernelGGL((pack_both_kernel<__bf16, 9>), grid, dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst_fwd, rows_total, (__bf16*)dst_dgrad, rows_d, kpad);
+        else hipLaunchKernelGGL((pack_both_kernel<__bf16, 1>), grid, dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst_fwd, rows_total, (__bf16*)dst_dgrad, rows_d, kpad);
+    } else {
+        if (k == 3) hipLaunchKernelGGL((pack_both_kernel<float, 9>), grid, dim3(256), 0, s, w_oihw, cout, cin, (float*)dst_fwd, rows_total, (float*)dst_dgrad, rows_d, kpad);
+        else hipLaunchKernelGGL((pack_both_kernel<float, 1>), grid, dim3(256), 0, s, w_oihw, cout, cin, (float*)dst_fwd, rows_total, (float*)dst_dgrad, rows_d, kpad);
+    }
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const Tens& dy, int H, int W, void* dx, bool accumulate, const void* wd_prepacked) {
     const int k = mode == MODE_P1 ? 1 : 3, kk = k * k;
     const size_t es = dsize(c.dtype);
     const int kpad = (int)align_up((size_t)cout, kalign(c.dtype));             // contraction length (forward cout), padded
     const int rows = conv_rows_pad(cin);
-    void* wd = c.ar->alloc((size_t)kk * rows * kpad * es);
+    void* wd = wd_prepacked ? const_cast<void*>(wd_prepacked) : c.ar->alloc((size_t)kk * rows * kpad * es);
     if (!wd) WDM_FAIL(WDM_ENOMEM, "workspace too small (dgrad weights)");
-    if (!c.dry) BY_DTYPE(c.dtype, l_pack_dgrad, c.s, w_oihw, cout, cin, kk, wd, rows, kpad);
+    if (!c.dry && !wd_prepacked) BY_DTYPE(c.dtype, l_pack_dgrad, c.s, w_oihw, cout, cin, kk, wd, rows, kpad);
     // what the transposed conv reads: dy (3x3 s1, 1x1, upsample), dy scattered onto the odd grid (Downsample); channel-padded if needed
     const void* src = dy.p;
     int Hs = dy.H, Ws = dy.W;
@@ -447,7 +486,7 @@ int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const T
     if (t_up) c.ar->free(t_up);
     if (t_pad) c.ar->free(t_pad);
     if (t_sc) c.ar->free(t_sc);
-    c.ar->free(wd);
+    if (!wd_prepacked) c.ar->free(wd);
     return rc;
 }
 

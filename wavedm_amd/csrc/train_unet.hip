@@ -304,7 +304,15 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
     ConvW w; w.cin = p.cin; w.cout = p.cout; w.k = p.k; w.rows_pad = conv_rows_pad(p.cout); w.b = P + p.b;
     void* pk = cx.ar->alloc(conv_packed_bytes(p.cin, p.cout, p.k, cx.dtype));
     if (!pk) WDM_FAIL(WDM_ENOMEM, "training workspace too small (packed weights)");
-    WDM_TRY(k_pack_conv(P + p.w, p.cout, p.cin, p.k, pk, w.rows_pad, 0, 1, cx.dtype, cx.s));
+    // the backward's transposed weights are written by the same pass over the fp32 parameters and kept until the tape reaches this conv
+    void* wd = nullptr;
+    if (x0->needs_grad) {
+        wd = cx.ar->alloc(conv_dgrad_packed_bytes(p.cin, p.cout, p.k, cx.dtype));
+        if (!wd) WDM_FAIL(WDM_ENOMEM, "training workspace too small (dgrad weights)");
+        WDM_TRY(k_pack_conv_both(P + p.w, p.cout, p.cin, p.k, pk, w.rows_pad, wd, cx.dtype, cx.s));
+    } else {
+        WDM_TRY(k_pack_conv(P + p.w, p.cout, p.cin, p.k, pk, w.rows_pad, 0, 1, cx.dtype, cx.s));
+    }
     w.w = pk;
     TT* o = new_act();
     WDM_TRY(run_conv(cx, w, mode, x0->t, x1 ? &x1->t : nullptr, nullptr, nullptr, temb_row >= 0 ? temb_all + temb_row : nullptr, temb_rows, 1, res ? &res->t : nullptr, &o->t,
@@ -312,7 +320,7 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
     cx.ar->free(pk);
     *out = o;
     const ConvP pp = p;
-    tape.push_back([this, pp, mode, x0, x1, temb_row, res, o]() -> int {
+    tape.push_back([this, pp, mode, x0, x1, temb_row, res, o, wd]() -> int {
         Ctx& cx = *c;
         if (!o->g) WDM_FAIL(WDM_ESTATE, "backward: conv output without gradient");
         const Tens dy = gtens(o);
@@ -323,16 +331,17 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
         if (x0->needs_grad) {
             if (!x1) {
                 bool first; WDM_TRY(grad_buf(x0, &first));
-                WDM_TRY(conv_dgrad(cx, mode, P + pp.w, pp.cin, pp.cout, dy, x0->t.H, x0->t.W, x0->g, !first));
+                WDM_TRY(conv_dgrad(cx, mode, P + pp.w, pp.cin, pp.cout, dy, x0->t.H, x0->t.W, x0->g, !first, wd));
             } else {
                 void* tmp = cx.ar->alloc((size_t)cx.B * x0->t.H * x0->t.W * pp.cin * dsize(cx.dtype));
                 if (!tmp) WDM_FAIL(WDM_ENOMEM, "training workspace too small (concat dgrad)");
-                WDM_TRY(conv_dgrad(cx, mode, P + pp.w, pp.cin, pp.cout, dy, x0->t.H, x0->t.W, tmp, false));
+                WDM_TRY(conv_dgrad(cx, mode, P + pp.w, pp.cin, pp.cout, dy, x0->t.H, x0->t.W, tmp, false, wd));
                 bool f0, f1; WDM_TRY(grad_buf(x0, &f0)); WDM_TRY(grad_buf(x1, &f1));
                 BYT(cx.dtype, l_split_add, cx.s, tmp, x0->t.C, x1->t.C, x0->g, f0 ? 0 : 1, x1->g, f1 ? 0 : 1, (long long)cx.B * x0->t.H * x0->t.W * pp.cin);
                 cx.ar->free(tmp);
             }
         }
+        if (wd) cx.ar->free(wd);
         WDM_HIP(hipGetLastError());
         return WDM_OK;
     });
