@@ -315,8 +315,9 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
     }
     w.w = pk;
     TT* o = new_act();
+    // want_stats: the conv's epilogue also leaves the GroupNorm partial statistics of its output (most conv outputs feed a GroupNorm)
     WDM_TRY(run_conv(cx, w, mode, x0->t, x1 ? &x1->t : nullptr, nullptr, nullptr, temb_row >= 0 ? temb_all + temb_row : nullptr, temb_rows, 1, res ? &res->t : nullptr, &o->t,
-                     Y_NHWC, nullptr, false));
+                     Y_NHWC, nullptr, true));
     cx.ar->free(pk);
     *out = o;
     const ConvP pp = p;
@@ -353,23 +354,26 @@ int wdm_trainer::op_gn_act(const NormP& p, TT* x0, TT* x1, int silu, TT** out) {
     Ctx& cx = *c;
     const int C = x0->t.C + (x1 ? x1->t.C : 0), HW = x0->t.H * x0->t.W;
     NormW nw; nw.g = P + p.g; nw.b = P + p.b; nw.c = C;
+    // partial statistics: taken from the producing conv's epilogue when the tensor carries them, else one pass over the tensor
     const int ns = gn_default_nslab(HW);
-    float* st0 = (float*)cx.ar->alloc(gn_stats_bytes(cx.B, ns, x0->t.C));
-    float* st1 = x1 ? (float*)cx.ar->alloc(gn_stats_bytes(cx.B, ns, x1->t.C)) : nullptr;
+    const bool own0 = x0->t.stats == nullptr, own1 = x1 && x1->t.stats == nullptr;
+    float* st0 = own0 ? (float*)cx.ar->alloc(gn_stats_bytes(cx.B, ns, x0->t.C)) : x0->t.stats;
+    float* st1 = !x1 ? nullptr : own1 ? (float*)cx.ar->alloc(gn_stats_bytes(cx.B, ns, x1->t.C)) : x1->t.stats;
+    const int ns0 = own0 ? ns : x0->t.nslab, ns1 = !x1 ? ns : own1 ? ns : x1->t.nslab;
     float* sc = (float*)cx.ar->alloc((size_t)cx.B * C * 4);
     float* sh = (float*)cx.ar->alloc((size_t)cx.B * C * 4);
     float* mr = (float*)cx.ar->alloc((size_t)cx.B * 64 * 4);          // kept for the backward pass
     if (!st0 || (x1 && !st1) || !sc || !sh || !mr) WDM_FAIL(WDM_ENOMEM, "training workspace too small (GroupNorm)");
     TT* o = new_act();
     WDM_TRY(alloc_tens(cx, C, x0->t.H, x0->t.W, &o->t));
-    WDM_TRY(k_gn_partial(x0->t, cx.B, st0, ns, cx.dtype, cx.s));
-    if (x1) WDM_TRY(k_gn_partial(x1->t, cx.B, st1, ns, cx.dtype, cx.s));
-    WDM_TRY(k_gn_finalize(cx.B, HW, st0, ns, x0->t.C, st1, ns, x1 ? x1->t.C : 0, nw, 1e-6f, 0, sc, sh, cx.s, mr));
+    if (own0) WDM_TRY(k_gn_partial(x0->t, cx.B, st0, ns, cx.dtype, cx.s));
+    if (own1) WDM_TRY(k_gn_partial(x1->t, cx.B, st1, ns, cx.dtype, cx.s));
+    WDM_TRY(k_gn_finalize(cx.B, HW, st0, ns0, x0->t.C, st1, ns1, x1 ? x1->t.C : 0, nw, 1e-6f, 0, sc, sh, cx.s, mr));
     WDM_TRY(k_gn_apply(x0->t, cx.B, sc, sh, C, o->t.p, C, 0, silu, cx.dtype, cx.s));
     if (x1) WDM_TRY(k_gn_apply(x1->t, cx.B, sc + x0->t.C, sh + x0->t.C, C, o->t.p, C, x0->t.C, silu, cx.dtype, cx.s));
     cx.ar->free(sh); cx.ar->free(sc);
-    if (st1) cx.ar->free(st1);
-    cx.ar->free(st0);
+    if (own1) cx.ar->free(st1);
+    if (own0) cx.ar->free(st0);
     *out = o;
     const NormP pp = p;
     tape.push_back([this, pp, x0, x1, silu, o, mr, C]() -> int {
