@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwavedm_hip.so")
+LIB_PATH = os.environ.get("WAVEDM_LIB") or os.path.join(_HERE, "csrc", "libwavedm_hip.so")     # WAVEDM_LIB: another build of the same ABI (A/B runs)
 
 WDM_F32, WDM_BF16 = 0, 1
 WDM_OK, WDM_EINVAL, WDM_ENOMEM, WDM_EHIP, WDM_ESTATE, WDM_ENOTFOUND = 0, -1, -2, -3, -4, -5

@@ -6,16 +6,16 @@
 // registers:
 //   * the weight tile of one dx column (3 taps x 128 cout x 32 ch = 24 KB) is a SUB-STAGE; a ring of three sub-stage buffers is
 //     filled two sub-stages ahead by DMA while the MFMAs of the current one run;
-//   * the halo tile of the NEXT channel slab (18 x 18 px x 32 ch, padded to 32 KB) is DMA'd raw into the second A buffer and
+//   * the halo tile of the NEXT channel slab (18 x 18 px x 32 ch, stored dense: 21 pieces of 1 KB) is DMA'd raw into the second A buffer and
 //     GroupNorm + SiLU is applied IN PLACE: every lane transforms exactly the 16-byte units it DMA'd itself (LDS-DMA is
 //     lane-linear), so the transform needs no barrier of its own, only the lane's own `vmcnt`;
 //   * out-of-image halo pixels / rows past the weight matrix are outside the buffer descriptors: the DMA writes zeros (the
 //     transform skips those units: padding comes after the activation, as in the reference);
 //   * GroupNorm scale/shift of the workgroup's image (<= 12 KB) sit in LDS, so the K loop has NO compiler-visible vector-memory
 //     instruction: every wait on the DMA queue is a counted `s_waitcnt vmcnt(N)` written here (hipcc would wait vmcnt(0)).
-// One raw barrier per sub-stage.  DMA issue per wave: 3 (+4 at the first sub-stage of a slab) 1 KB pieces per 48 MFMAs.
+// One raw barrier per sub-stage.  DMA issue per wave: 3 (+3 at the first sub-stage of a slab) 1 KB pieces per 48 MFMAs.
 //
-// LDS map (bytes): A[2] = 2 x 32 KB at 0, weight ring = 3 x 24 KB at 64 KB, scale/shift at 136 KB (2 x Cin floats).
+// LDS map (bytes): A[2] = 2 x 24 KB at 0, weight ring = 3 x 24 KB at 48 KB, scale/shift at 120 KB (2 x Cin floats).
 // The LDS image of both operands is conv_kernel.h's: 64-byte rows, unit u of row q in slot 4q + (u ^ ((q>>1)&2)); a DMA piece
 // covers 16 rows, lane L writes slot L of the piece, i.e. it FETCHES unit (L&3) ^ ((L>>3)&2) of row L>>2 -- a function of the
 // lane only, so each lane needs one scale/shift unit per slab.
@@ -30,17 +30,21 @@ template <int WAVES_M_, int WAVES_N_, int WM_, int WN_>
 struct ConvDmaCfgT {
     static constexpr int TH = 16, TW = 16, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_;
     static constexpr int NWAVES = WAVES_M * WAVES_N, NTHREADS = 64 * NWAVES, BN = 16 * WN * WAVES_N, BK = 32;
-    static constexpr int A_CPW = 32 / NWAVES, B_CPW = 24 / NWAVES;         // DMA pieces per wave: halo slab / weight sub-stage
-    static_assert(16 * WM * WAVES_M == 256 && BN == 128 && 32 % NWAVES == 0 && 24 % NWAVES == 0, "256 x 128 tile");
-    static constexpr int PH = 18, PW = 18, RS = 24;
-    static constexpr int A_ROWS = PH * RS;                      // 432 row slots used
-    static constexpr int A_BYTES = 32 * 1024;                   // 512 row slots: 32 DMA pieces, 4 per wave
+    static constexpr int A_CPW = 24 / NWAVES, B_CPW = 24 / NWAVES;         // DMA pieces per wave: halo slab / weight sub-stage
+    static_assert(16 * WM * WAVES_M == 256 && BN == 128 && 24 % NWAVES == 0, "256 x 128 tile");
+    // the 18 x 18 halo is stored DENSE (row stride 18 pixel slots): 324 slots = 21 DMA pieces instead of 27 with an 8-aligned stride, i.e.
+    // three pieces per wave to fetch and to GroupNorm+SiLU instead of four.  The unit rotation (q >> 1) & 2 then differs from halo row to
+    // halo row, so the fragment addresses are kept per (row, dx) instead of one per dx.
+    static constexpr int PH = 18, PW = 18, RS = 18;
+    static constexpr int A_ROWS = PH * RS;                      // 324 row slots used
+    static constexpr int A_BYTES = 24 * 1024;                   // 384 row slots: 24 DMA pieces, 3 per wave
     static constexpr int B_SUB = 3 * BN * 64;                   // 24 KB: 24 pieces, 3 per wave
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int SC_OFF = B_OFF + 3 * B_SUB;            // 136 KB
+    static constexpr int SC_OFF = B_OFF + 3 * B_SUB;            // 120 KB
     static constexpr int MAX_CIN = 2048;
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
-    static constexpr int LDS_BYTES = SC_OFF + 2 * MAX_CIN * 4;  // 152 KB
+    static constexpr int G_RING = 3 * (256 * 128 + BN * 128);   // the shortcut phase's three 48 KB stages overlay everything (144 KB)
+    static constexpr int LDS_BYTES = (SC_OFF + 2 * MAX_CIN * 4 > G_RING) ? SC_OFF + 2 * MAX_CIN * 4 : G_RING;
     static_assert(EPI_BYTES <= SC_OFF, "epilogue tile must not overlap the scale/shift table");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -159,12 +163,14 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
 
     // ---- fragment addresses (as conv_kernel.h)
     const int ku = lane >> 4;
-    int a_addr[3];
+    int a_addr[WM + 2][3];
     {
         const int m = wave_m * WM * 16 + (lane & 15);
         const int ly = m / TW, lx = m % TW;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) a_addr[dx] = lds_off(ly * RS + lx + dx, ku);
+        for (int r = 0; r < WM + 2; ++r)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a_addr[r][dx] = lds_off((ly + r) * RS + lx + dx, ku);
     }
     int b_addr[WN];
 #pragma unroll
@@ -177,11 +183,11 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
-        const char* pa = smem + (s & 1) * C::A_BYTES + a_addr[dx];
+        const char* pa = smem + (s & 1) * C::A_BYTES;
         const char* pb = smem + dx * C::B_SUB;
         uint4 ah[WM + 2];
 #pragma unroll
-        for (int r = 0; r < WM + 2; ++r) ah[r] = *(const uint4*)(pa + r * (RS * 64));
+        for (int r = 0; r < WM + 2; ++r) ah[r] = *(const uint4*)(pa + a_addr[r][dx]);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             uint4 bfr[WN];
