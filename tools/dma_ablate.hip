@@ -1,0 +1,48 @@
+// Ablation micro-benchmark of the LDS-DMA 3x3 conv kernel (not part of the library): one layer shape, phases switched off by
+// -DWDM_DABL=<mask> (conv_dma_kernel.h: 1 transform, 2 MFMAs, 4 halo DMA, 8 weight DMA, 16 fragment reads with 2).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWDM_DABL=<m> -I wavedm_amd/csrc -I include tools/dma_ablate.hip -o tools/abl_dma_<m>
+// run:   tools/abl_dma_<m> [B H Cin Cout pro]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "conv_dma_kernel.h"
+using namespace wdm;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 16, Cin = argc > 3 ? atoi(argv[3]) : 512, Cout = argc > 4 ? atoi(argv[4]) : 512;
+    const int pro = argc > 5 ? atoi(argv[5]) : 1;
+    const size_t nx = (size_t)B * H * H * Cin, ny = (size_t)B * H * H * Cout, nw = (size_t)9 * Cout * Cin;
+    unsigned short *x, *y, *w; float *sc, *sh, *bias;
+    CK(hipMalloc(&x, nx * 2)); CK(hipMalloc(&y, ny * 2)); CK(hipMalloc(&w, nw * 2));
+    CK(hipMalloc(&sc, (size_t)B * Cin * 4)); CK(hipMalloc(&sh, (size_t)B * Cin * 4)); CK(hipMalloc(&bias, Cout * 4));
+    std::vector<unsigned short> hx(nx), hw(nw);
+    srand(1);
+    for (auto& v : hx) v = (unsigned short)(0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15));
+    for (auto& v : hw) v = (unsigned short)(0x3c00 + (rand() & 0xff) + ((rand() & 1) << 15));
+    CK(hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    std::vector<float> ones((size_t)B * Cin, -1.4426950408889634f);
+    CK(hipMemcpy(sc, ones.data(), ones.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(sh, 0, ones.size() * 4)); CK(hipMemset(bias, 0, Cout * 4));
+    ConvArgs a{};
+    a.x0 = x; a.C0 = Cin; a.xs0 = Cin; a.B = B; a.Hin = a.Win = a.Hout = a.Wout = H; a.Cin = Cin; a.Cout = Cout;
+    a.w = w; a.w_tap_stride = (long long)Cout * Cin; a.w_row_stride = Cin; a.w_rows = Cout; a.bias = bias; a.alpha = 1.f;
+    a.pro = pro; a.scale = sc; a.shift = sh; a.y = y; a.y_mode = Y_NHWC; a.y_s = Cout;
+    a.x0_bytes = (unsigned)(nx * 2); a.w_bytes = (unsigned)(nw * 2);
+    using C = ConvDmaCfg;
+    auto kern = conv_dma_kernel<4, 2, 4, 4>;
+    a.mtiles = B * (H / 16) * (H / 16); a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;
+    const int grid = 8 * a.ntiles * ((a.mtiles + 7) / 8);
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, 0, a);
+    CK(hipDeviceSynchronize());
+    const int it = 20;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, 0, a);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double fl = 2.0 * B * H * H * Cout * 9.0 * Cin;
+    printf("DABL=%2d B=%d H=%d %d->%d pro=%d grid=%d : %7.1f us  %7.1f TFLOP/s (nominal)\n", WDM_DABL, B, H, Cin, Cout, pro, grid, ms / it * 1e3, fl / (ms / it) / 1e9);
+    return 0;
+}

@@ -22,6 +22,12 @@
 #pragma once
 #include "conv_kernel.h"
 
+// tools/dma_ablate.hip builds this kernel with phases switched off (0 in the library): 1 no GroupNorm+SiLU transform, 2 no MFMAs (the
+// fragment reads stay), 4 no halo DMA after slab 0, 8 no weight DMA after the prologue, 16 no fragment reads either (with 2)
+#ifndef WDM_DABL
+#define WDM_DABL 0
+#endif
+
 namespace wdm {
 
 // WAVES_M x WAVES_N waves, each a (16 WM) x (16 WN) sub-tile of the 256 x 128 output tile: 4x2 waves of 64x64 (8 waves, two per
@@ -127,6 +133,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     // weight sub-stage (slab s, column j) -> ring buffer `ring`; slabs past the end are clamped (the extra pieces land in buffers
     // nobody reads again and keep the per-sub-stage DMA counts, hence the vmcnt constants, uniform)
     auto issue_b = [&](int s, int j, int ring) __attribute__((always_inline)) {
+        if ((WDM_DABL & 8) && s > 0) return;
         const int sc_ = s < nslab ? s : nslab - 1;
         const int soff = (int)(((long long)j * a.w_tap_stride + sc_ * C::BK) * 2);
         const unsigned base = lds0 + C::B_OFF + ring * C::B_SUB;
@@ -134,6 +141,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         for (int i = 0; i < BCP; ++i) dma16(q_w, base + (wave * BCP + i) * 1024, b_v[i], soff);
     };
     auto issue_a = [&](int s) __attribute__((always_inline)) {        // raw halo tile of slab s (clamped) -> A[s & 1]
+        if ((WDM_DABL & 4) && s > 0) return;
         const int sc_ = s < nslab ? s : nslab - 1;
         const int c = sc_ * C::BK;
         const unsigned base = lds0 + (s & 1) * C::A_BYTES;
@@ -148,6 +156,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     // GroupNorm + SiLU in place on the units this lane fetched for slab s
     const float* sct = (const float*)(smem + C::SC_OFF);
     auto transform = [&](int s) __attribute__((always_inline)) {
+        if (WDM_DABL & 1) return;
         const int c = (s < nslab ? s : nslab - 1) * C::BK + un * 8;
         float sc[8], sh[8];
         *(float4*)&sc[0] = *(const float4*)(sct + c); *(float4*)&sc[4] = *(const float4*)(sct + c + 4);
@@ -183,6 +192,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
+        if ((WDM_DABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
         const char* pb = smem + dx * C::B_SUB;
         uint4 ah[WM + 2];
@@ -196,7 +206,10 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], ah[i + dy], bfr[j]);
+                for (int j = 0; j < WN; ++j) {
+                    if (WDM_DABL & 2) { if (i == 0) acc[0][j][0] += __uint_as_float(bfr[j].x ^ ah[dy + (j & 3)].x); }   // one VALU per fragment keeps the reads alive
+                    else mma16<T>(acc[i][j], ah[i + dy], bfr[j]);
+                }
         }
     };
 #define WDM_DMA_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
