@@ -4,8 +4,8 @@
 // Why a second kernel: in conv_kernel.h every stage moves 12 KB per wave through registers (12 buffer loads + 12 ds_write_b128,
 // ~100 + ~75 issue cycles each, 48 staging VGPRs), in phases during which the matrix pipe idles.  Here nothing is staged through
 // registers:
-//   * the weight tile of one dx column (3 taps x 128 cout x 32 ch = 24 KB) is a SUB-STAGE; a ring of three sub-stage buffers is
-//     filled two sub-stages ahead by DMA while the MFMAs of the current one run;
+//   * the weight tile of one dx column (3 taps x 128 cout x 32 ch = 24 KB) is a SUB-STAGE; a ring of four sub-stage buffers is
+//     filled three sub-stages ahead by DMA while the MFMAs of the current one run;
 //   * the halo tile of the NEXT channel slab (18 x 18 px x 32 ch, stored dense: 21 pieces of 1 KB) is DMA'd raw into the second A buffer and
 //     GroupNorm + SiLU is applied IN PLACE: every lane transforms exactly the 16-byte units it DMA'd itself (LDS-DMA is
 //     lane-linear), so the transform needs no barrier of its own, only the lane's own `vmcnt`;
@@ -15,7 +15,7 @@
 //     instruction: every wait on the DMA queue is a counted `s_waitcnt vmcnt(N)` written here (hipcc would wait vmcnt(0)).
 // One raw barrier per sub-stage.  DMA issue per wave: 3 (+3 at the first sub-stage of a slab) 1 KB pieces per 48 MFMAs.
 //
-// LDS map (bytes): A[2] = 2 x 24 KB at 0, weight ring = 3 x 24 KB at 48 KB, scale/shift at 120 KB (2 x Cin floats).
+// LDS map (bytes): A[2] = 2 x 24 KB at 0, weight ring = 4 x 24 KB at 48 KB, scale/shift at 144 KB (2 x Cin floats): 160 KB.
 // The LDS image of both operands is conv_kernel.h's: 64-byte rows, unit u of row q in slot 4q + (u ^ ((q>>1)&2)); a DMA piece
 // covers 16 rows, lane L writes slot L of the piece, i.e. it FETCHES unit (L&3) ^ ((L>>3)&2) of row L>>2 -- a function of the
 // lane only, so each lane needs one scale/shift unit per slab.
@@ -46,7 +46,8 @@ struct ConvDmaCfgT {
     static constexpr int A_BYTES = 24 * 1024;                   // 384 row slots: 24 DMA pieces, 3 per wave
     static constexpr int B_SUB = 3 * BN * 64;                   // 24 KB: 24 pieces, 3 per wave
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int SC_OFF = B_OFF + 3 * B_SUB;            // 120 KB
+    static constexpr int NRING = 4;                             // weight sub-stages in LDS: the current one and three in flight
+    static constexpr int SC_OFF = B_OFF + NRING * B_SUB;        // 144 KB
     static constexpr int MAX_CIN = 2048;
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
     static constexpr int G_RING = 3 * (256 * 128 + BN * 128);   // the shortcut phase's three 48 KB stages overlay everything (144 KB)
@@ -191,10 +192,10 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
+    auto mfma_dx = [&](int s, int dx, int slot) __attribute__((always_inline)) {
         if ((WDM_DABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
-        const char* pb = smem + dx * C::B_SUB;
+        const char* pb = smem + slot * C::B_SUB;
         uint4 ah[WM + 2];
 #pragma unroll
         for (int r = 0; r < WM + 2; ++r) ah[r] = *(const uint4*)(pa + a_addr[r][dx]);
@@ -214,11 +215,15 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     };
 #define WDM_DMA_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-    // ---- prologue: scale/shift table, slab 0 halo, first two weight sub-stages
+    // ---- prologue: scale/shift table, slab 0 halo, the first three weight sub-stages
+    // Sub-stage g = 3 s + dx reads ring slot g & 3; its weights are issued THREE sub-stages ahead and the halo slab of s + 1 at (s, 0), to be
+    // transformed at the end of (s, 2).  The DMA queue retires in order, so a wait for weights also waits for every halo piece issued before
+    // them: with three sub-stages of lead the (HBM-resident, 64-byte-gathered) halo pieces are no longer the ones the weight waits block on.
     const bool pro = a.pro != 0;
     issue_a(0);
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
+    issue_b(0, 2, 2);
     if (pro) {
         float* w = (float*)(smem + C::SC_OFF);
         const float* ps = a.scale + (long long)img0 * a.Cin;
@@ -228,19 +233,28 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         __builtin_amdgcn_sched_barrier(0);
         transform(0);
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    int g = 0;
     for (int s = 0; s < nslab; ++s) {
-        if (s == 0 && pro) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        else WDM_DMA_SYNC(BCP);
-        issue_b(s, 2, 2);
+        issue_b(s + 1, 0, (g + 3) & 3);          // slot of sub-stage g - 1
         issue_a(s + 1);
-        mfma_dx(s, 0);
-        WDM_DMA_SYNC(BCP + ACP);
-        issue_b(s + 1, 0, 0);
-        mfma_dx(s, 1);
-        WDM_DMA_SYNC(BCP);
-        issue_b(s + 1, 1, 1);
-        if (pro) transform(s + 1);
-        mfma_dx(s, 2);
+        mfma_dx(s, 0, g & 3);
+        WDM_DMA_SYNC(2 * BCP + ACP);             // weights of g + 1 are in; g + 2, g + 3 and the halo slab may be in flight
+        ++g;
+        issue_b(s + 1, 1, (g + 3) & 3);
+        mfma_dx(s, 1, g & 3);
+        WDM_DMA_SYNC(2 * BCP + ACP);             // weights of g + 1 (issued before the halo slab) are in
+        ++g;
+        issue_b(s + 1, 2, (g + 3) & 3);
+        mfma_dx(s, 2, g & 3);
+        if (pro) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BCP) : "memory");      // the halo slab of s + 1 (this lane's pieces) has landed
+            __builtin_amdgcn_sched_barrier(0);
+            transform(s + 1);
+        }
+        WDM_DMA_SYNC(2 * BCP);                   // halo slab and weights of g + 1 in; transform visible after the barrier
+        ++g;
     }
 #undef WDM_DMA_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // no DMA may land on what follows
