@@ -201,6 +201,11 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         for (int r = 0; r < WM + 2; ++r) ah[r] = *(const uint4*)(pa + a_addr[r][dx]);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
+            // The two waves of a SIMD are served oldest first: left alone, the older one takes every MFMA slot while it has operands, finishes
+            // its 48 MFMAs in ~1200 cycles and then idles ~900 cycles at the barrier while the younger one, alone with its LDS waits, needs
+            // ~2100 (s_memtime stamps of the eight waves).  A priority that falls with progress inside the sub-stage lets the wave that is
+            // behind win the slot (three levels, one per tap row; finer steps inside a row measured no better).
+            if (dy == 0) __builtin_amdgcn_s_setprio(2); else if (dy == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             uint4 bfr[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dy * (BN * 64));
