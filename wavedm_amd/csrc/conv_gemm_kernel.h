@@ -178,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         const char* base = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // see conv_dma_kernel.h
             uint4 af[WM], bfr[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a_off[ks] + i * (16 * 128));

@@ -665,6 +665,8 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
             // read the WM+2 halo rows once per dx and reuse them for the three dy taps (18 A reads instead of 36)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
+                // wave priority falling with progress inside the stage (conv_dma_kernel.h explains): the wave that is behind wins the MFMA slot
+                if (dx == 0) __builtin_amdgcn_s_setprio(2); else if (dx == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 uint4 ah[WM + 2];
 #pragma unroll
                 for (int r = 0; r < WM + 2; ++r) ah[r] = *(const uint4*)(smem + a_addr[0][dx] + r * (RS * 64));
@@ -689,6 +691,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             if (MODE == MODE_P1 && s >= nsub) break;
+            if (NSUB >= 3) { if (s == 0) __builtin_amdgcn_s_setprio(2); else if (s == NSUB / 3) __builtin_amdgcn_s_setprio(1); else if (s == 2 * NSUB / 3) __builtin_amdgcn_s_setprio(0); }
             uint4 af[WM], bfr[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) {

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
             for (int r = 0; r < WM + 1; ++r) ah[r] = *(const uint4*)(pa + a_addr[0][dxl] + r * (RS * 64));
 #pragma unroll
             for (int dyl = 0; dyl < 2; ++dyl) {
+                if (dyl == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // see conv_dma_kernel.h
                 uint4 bfr[WN];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
         } else {
 #pragma unroll
             for (int dyl = 0; dyl < 2; ++dyl) {
+                if (dyl == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 uint4 af[WM], bfr[WN];
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(pa + a_addr[i % NAI][dxl] + dyl * (RS * 64));
