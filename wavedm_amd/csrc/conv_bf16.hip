@@ -4,4 +4,5 @@
 #include "conv_gemm_kernel.h"
 #include "conv_dma_kernel.h"
 #include "conv_up4_kernel.h"
+#include "conv_dma8_kernel.h"
 #include "conv_dispatch.inc"
