@@ -203,9 +203,13 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 // 8x8 tiles always use half-image slabs (32 rows) whether one or two images share a workgroup.
 __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { return (TH * TW == 64) ? (EROWS < 32 ? EROWS : 32) : EROWS; }
 
+#ifndef WDM_EABL
+#define WDM_EABL 0          // tools/dma_ablate.hip: 1 = no global stores of the output tile, 2 = return at once
+#endif
 template <typename T, int TH, int TW, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
                                               int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
+    if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int VEC = TI<T>::VEC;
     constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
     constexpr int ECOLS = 16 * NJ;
@@ -307,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 float vr[8];                                   // the values as the consumer will read them back
                 if (a.y_mode == Y_NHWC) {
                     T* yp = (T*)a.y + opix * a.y_s + n;
-                    if (VEC == 8) { const uint4 pk = TI<T>::pack(v); TI<T>::unpack(pk, vr); if (valid) *(uint4*)yp = pk; }
+                    if (VEC == 8) { const uint4 pk = TI<T>::pack(v); TI<T>::unpack(pk, vr); if (valid && !(WDM_EABL & 1)) *(uint4*)yp = pk; }
                     else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) vr[e] = v[e];
