@@ -220,7 +220,9 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     }
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
-    const bool fuse_nin = w.has_nin && !pass && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
+    // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h unless WDM_DMA8=0)
+    const char* e8 = getenv("WDM_DMA8");
+    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && !(e8 && e8[0] == '0'))) && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
                           conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
     if (w.has_nin && !fuse_nin) {
@@ -230,7 +232,8 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     if (pass) {
         Tens a2;
         WDM_TRY(materialize_gn_silu(c, w.n2, t1, nullptr, &a2));
-        WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
         free_tens(c, a2);
     } else {
         WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));

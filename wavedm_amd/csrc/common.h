@@ -149,7 +149,9 @@ void prof_end(hipStream_t s);
 
 // shapes whose 3x3 conv can also accumulate a 1x1 shortcut over [sC0 | sC1] channels (conv_dma_kernel.h; bf16 only)
 inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int sC1) {
-    return H % 16 == 0 && W % 16 == 0 && cout >= 128 && cin % 32 == 0 && cin <= 2048 && sC0 % 64 == 0 && (sC0 + sC1) % 64 == 0;
+    const bool t16 = H % 16 == 0 && W % 16 == 0 && cout >= 128 && cin <= 2048;      // conv_dma_kernel.h
+    const bool t8 = H == 8 && W == 8;                                                // conv_dma8_kernel.h (convs without the GroupNorm prologue)
+    return (t16 || t8) && cin % 32 == 0 && sC0 % 64 == 0 && (sC0 + sC1) % 64 == 0;
 }
 
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------

@@ -166,6 +166,78 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 #undef WDM_DMA8_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // no DMA may land on what follows
     __builtin_amdgcn_sched_barrier(0);
+
+    // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1), as in
+    // conv_dma_kernel.h: a plain GEMM over the tile's 128 pixels, 64 channels per K step, three 24 KB stages over the idle operand buffers
+    if (a.sx0 != nullptr) {
+        constexpr int G_A = 128 * 128, G_STAGE = G_A + BN * 128;
+        static_assert(3 * G_STAGE <= C::LDS_BYTES, "shortcut ring");
+        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
+        unsigned g_a0[4], g_a1[4], g_b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + (lane >> 3);          // 0..127: image row / 64, pixel row % 64
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = img0 + row / 64 < a.B;
+            const unsigned gp = (unsigned)((img0 + row / 64) * 64 + row % 64);
+            g_a0[i] = ok ? gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16) : OOB;
+            g_a1[i] = ok ? gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);          // 0..63
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
+        }
+        auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
+            const int c = k * 64;
+            const unsigned base = lds0 + buf * G_STAGE;
+            if (c < a.sC0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16(q_s0, base + (wave * 4 + i) * 1024, g_a0[i], c * 2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16(q_s1, base + (wave * 4 + i) * 1024, g_a1[i], (c - a.sC0) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16(q_sw, base + G_A + (wave * 2 + i) * 1024, g_b[i], c * 2);
+        };
+        const int sw7 = (lane >> 1) & 7;
+        int a2[2], b2[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = (ks * 4 + ku) ^ sw7;
+            a2[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
+            b2[ks] = G_A + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
+        }
+        const int nk = (a.sC0 + a.sC1) / 64;
+        issue2(0, 0);
+        if (nk > 1) issue2(1, 1);
+        int buf = 0;
+        for (int k = 0; k < nk; ++k) {
+            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2);
+            const char* base = smem + buf * G_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(base + b2[ks] + j * (16 * 128));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0);
 }
 
