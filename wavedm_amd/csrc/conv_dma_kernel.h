@@ -49,7 +49,7 @@ struct ConvDmaCfgT {
     static constexpr int NRING = 4;                             // weight sub-stages in LDS: the current one and three in flight
     static constexpr int SC_OFF = B_OFF + NRING * B_SUB;        // 144 KB
     static constexpr int MAX_CIN = 2048;
-    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
+    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * WN + 4) * 4;     // one-pass epilogue: 64 x 68 floats per wave
     static constexpr int G_RING = 3 * (256 * 128 + BN * 128);   // the shortcut phase's three 48 KB stages overlay everything (144 KB)
     static constexpr int LDS_BYTES = (SC_OFF + 2 * MAX_CIN * 4 > G_RING) ? SC_OFF + 2 * MAX_CIN * 4 : G_RING;
     static_assert(EPI_BYTES <= SC_OFF, "epilogue tile must not overlap the scale/shift table");
@@ -336,7 +336,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    conv_epilogue<T, TH, TW, WM, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm

@@ -206,12 +206,12 @@ __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { re
 #ifndef WDM_EABL
 #define WDM_EABL 0          // tools/dma_ablate.hip: 1 = no global stores of the output tile, 2 = return at once
 #endif
-template <typename T, int TH, int TW, int WM, int WN>
+template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
                                               int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int VEC = TI<T>::VEC;
-    constexpr int NJ = (WN >= 2) ? 2 : 1;            // 16-column fragments per pass
+    constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);   // 16-column fragments per pass (NJ_ = WN: one pass, whole 128-byte rows per wave)
     constexpr int ECOLS = 16 * NJ;
     constexpr int ESTR = ECOLS + 4;                   // row stride (floats): 4*ESTR = 16 (mod 32) -> conflict-free writes
     constexpr int EROWS = 16 * WM;
