@@ -35,7 +35,7 @@ struct GemmCfg {
     static constexpr int A_BYTES = M * 128;
     static constexpr int B_BYTES = BN * 128;
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * (WN >= 2 ? 2 : 1) + 4) * 4;
+    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * WN + 4) * 4;       // one-pass epilogue (whole 128-byte rows per wave)
     static constexpr int NBUF = 3;                                  // LDS ring: two stages in flight while one is consumed
     static constexpr int LDS_BYTES = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
     static constexpr int A_CPW = (M / 8) / NWAVES;                  // 1 KB chunks (8 rows) per wave per stage
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         if (t == 123.456f) ((float*)a.y)[tid] = t;
         return;
     }
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    conv_epilogue<T, TH, TW, WM, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm

@@ -31,8 +31,9 @@ struct ConvUp4Cfg {
     static constexpr int A_BYTES = A_CPW * 8 * 1024;            // 32 KB / 40 KB
     static constexpr int B_SUB = 2 * BN * 64;                   // 16 KB
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 112 KB / 128 KB
-    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
+    static constexpr int EPI_NJ = TILE == 16 ? WN : 2;          // 16 x 16 tiles: one-pass epilogue (whole 128-byte rows per wave), 136 KB
+    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * EPI_NJ + 4) * 4;
+    static constexpr int LDS_BYTES = (B_OFF + 3 * B_SUB > EPI_BYTES) ? B_OFF + 3 * B_SUB : EPI_BYTES;
     static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #undef WDM_UP4_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
+    conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
 }
 
 }  // namespace wdm
