@@ -129,21 +129,26 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // A 16-row MFMA group is two image rows (2i, 2i + 1).  Tap row dy = 2 of group i is tap row 0 of group i + 1, so per dx column the wave
+    // reads five "even" row pairs (rows 2j, 2j + 1: dy = 0 and 2) and four "odd" ones (rows 2j + 1, 2j + 2: dy = 1) -- nine fragment reads
+    // instead of twelve (these layers are LDS-bound).  Wave row wave_m is image wave_m of the tile, so group i + 1 = WM is halo rows 8, 9.
     auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
         const char* pa = smem + (s & 1) * C::A_BYTES;
         const char* pb = smem + dx * C::B_SUB;
+        uint4 ae[WM + 1], ao[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) { ae[i] = *(const uint4*)(pa + a_addr[i][dx]); ao[i] = *(const uint4*)(pa + a_addr[i][dx] + RS * 64); }
+        ae[WM] = *(const uint4*)(pa + a_addr[WM - 1][dx] + 2 * (RS * 64));
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             if (dy == 0) __builtin_amdgcn_s_setprio(2); else if (dy == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // conv_dma_kernel.h
-            uint4 af[WM], bfr[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(pa + a_addr[i][dx] + dy * (RS * 64));
+            uint4 bfr[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dy * (BN * 64));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], dy == 0 ? ae[i] : dy == 1 ? ao[i] : ae[i + 1], bfr[j]);
         }
     };
 #define WDM_DMA8_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
