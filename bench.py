@@ -217,7 +217,7 @@ def main():
     if rank == 0:
         total_imgs = B * world * args.steps
         res = {
-            "metric": "restored images/sec, raindrop 64x64 patches, 100-step DDIM" if args.workload == "c1" else
+            "metric": f"restored images/sec, raindrop 64x64 patches, {args.ddim_steps}-step DDIM" if args.workload == "c1" else
                       f"restored images/sec, workload {args.workload} (informational, not the headline metric)",
             "value": round(total_imgs / elapsed, 3),
             "unit": "img/s",
