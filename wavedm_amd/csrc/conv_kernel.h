@@ -206,10 +206,11 @@ __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { re
 #ifndef WDM_EABL
 #define WDM_EABL 0          // tools/dma_ablate.hip: 1 = no global stores of the output tile, 2 = return at once
 #endif
-template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
-                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
-    if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
+// `write_pass(ep, jp)` puts the wave's accumulators of the 16-column fragments [jp, jp + NJ) into its fp32 tile ep[row][ESTR] (row = pixel of the wave
+// tile in row-major order); it is the only part that knows the MFMA C layout (16x16 fragments below, 32x32 ones in conv_pp_kernel.h).
+template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass>
+__device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
+                                                int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
     constexpr int VEC = TI<T>::VEC;
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);   // 16-column fragments per pass (NJ_ = WN: one pass, whole 128-byte rows per wave)
     constexpr int ECOLS = 16 * NJ;
@@ -256,14 +257,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
         // main loop (other waves may still read the operand images this tile overlays) needs the workgroup barrier.
         if (jp == 0) __syncthreads();
         else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-        if (active)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
+        if (active) write_pass(ep, jp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (!active) continue;
@@ -399,6 +393,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
             }
         }
     }
+}
+
+template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
+                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
+    if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
+    constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
+    constexpr int ESTR = 16 * NJ + 4;
+    auto write_pass = [&](float* ep, int jp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
+    };
+    conv_epilogue_w<T, TH, TW, WM, WN, NJ_>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
 }
 
 // ------------------------------------------------------------------------------------------------
