@@ -54,8 +54,9 @@ def main(argv=None):
         raise SystemExit("wavedm_run: no GPU visible (the package has no CPU path)")
     torch.cuda.set_device(args.local_rank)
     config.device = torch.device("cuda", args.local_rank)
-    seed = args.seed + (args.rank if args.mode == "train" else 0)
-    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+    def reseed(seed):
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+    reseed(args.seed)            # every rank builds the SAME initial model (train_diffusion.py:74-77 seeds all ranks identically)
     if args.world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")          # RCCL
@@ -65,7 +66,12 @@ def main(argv=None):
     DATASET = datasets.__dict__[config.data.dataset](args, config)
     diffusion = wavedm_amd.DenoisingDiffusion_Wavelet(args, config, dtype=args.dtype)
     if args.mode == "train":
+        # only now do the ranks diverge: noise, timesteps and crop positions differ per rank (the trainer also broadcasts rank 0's
+        # parameters when it is built, as DistributedDataParallel does at construction, ddm_wavelet.py:168)
+        reseed(args.seed + args.rank)
         diffusion.train(DATASET, max_steps=args.max_steps)
+        if args.world_size > 1:
+            dist.destroy_process_group()
         return 0
     if args.ema and args.resume:
         diffusion.load_ddm_ckpt(args.resume, ema=True)

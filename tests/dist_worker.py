@@ -1,6 +1,7 @@
-"""Worker for the 2-rank GPU tests (tests/test_gpu_dist.py): launched by torch.distributed.run with the gloo backend so that
-both ranks can share the single GPU of the test box.  Exercises the N > 1 code paths of wavedm_amd.parallel / sampling on
-the real HIP kernels: image-sharded restore + all-gather, weight broadcast + adopt, and the patch-sharded sampler."""
+"""Worker for the 2-rank GPU tests, launched by torch.distributed.run.  WDM_TEST_BACKEND=gloo (tests/test_gpu_dist.py): both ranks share
+cuda:0, so the N > 1 code paths run on the real HIP kernels on a one-GPU box.  WDM_TEST_BACKEND=nccl (tests/test_gpu_rccl.py, needs two
+devices): one rank per GPU over RCCL -- the deployment shape (eval_diffusion.py:83, ddm_wavelet.py:168 in the reference).
+Exercised: weight broadcast + adopt, image-sharded restore + all-gather, the patch-sharded sampler, the gradient all-reduce."""
 import os
 import sys
 
@@ -17,13 +18,17 @@ def main(out_path):
     import wavedm_amd
     from wavedm_amd import parallel, procedural as P
     torch.set_grad_enabled(False)
-    dist.init_process_group(backend="gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", 0)
+    backend = os.environ.get("WDM_TEST_BACKEND", "gloo")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    else:
+        dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     cfg = P.reduced_config()
     cfg.device = dev
-    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)
+    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=dev.index, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)
     d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
     if rank == 0:                                   # only rank 0 "has the checkpoint"
         d.model.load_state_dict(P.procedural_state_dict(cfg), strict=True)
@@ -53,8 +58,22 @@ def main(out_path):
     tr.loss_and_grads(bx[lo:hi].to(dev), bt[lo:hi], be[lo:hi].to(dev))
     tr.allreduce_grads()
     tr.optimizer_step()
+    # (4) from-scratch training, no --resume: the ranks build DIFFERENT random models (the ADVICE r1 scenario); make_trainer() must leave
+    # every rank with rank 0's parameters, as DistributedDataParallel's construction-time broadcast does (ddm_wavelet.py:168)
+    torch.manual_seed(1000 + rank)
+    d4 = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
+    t4 = d4.make_trainer(dtype="f32")
+    own = torch.cat([p.detach().flatten() for p in d4.model.parameters()]).to(dev)       # this rank's own random initialisation
+    owns = [torch.empty_like(own) for _ in range(world)]
+    dist.all_gather(owns, own)
+    mine = t4.params.clone()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok = (not torch.equal(owns[0], owns[1])) and all(torch.equal(b, both[0]) for b in both) and torch.equal(t4.ema, t4.params)
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        torch.save({"out_img": out_img.cpu(), "xs_last": xs[-1].cpu(), "x0_m5": x0[-5].cpu(), "world": world,
+        torch.save({"out_img": out_img.cpu(), "fresh_init_synced": bool(flag.item() == 1.0), "xs_last": xs[-1].cpu(), "x0_m5": x0[-5].cpu(), "world": world,
                     "grads": tr.grads.cpu(), "params1": tr.params.cpu()}, out_path)
     dist.barrier()
     dist.destroy_process_group()

@@ -17,10 +17,11 @@ torch.set_grad_enabled(False)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_ranks_match_single_process(tmp_path):
+def run_two_ranks(tmp_path, backend):
+    """Launch tests/dist_worker.py on 2 ranks with `backend` and compare what rank 0 saved with the single-process results."""
     import wavedm_amd
     out = tmp_path / "dist.pt"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", WDM_TEST_BACKEND=backend)
     import socket
     with socket.socket() as sock:                      # a free rendezvous port on this box
         sock.bind(("127.0.0.1", 0))
@@ -31,6 +32,7 @@ def test_two_ranks_match_single_process(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out)
     assert got["world"] == 2
+    assert got["fresh_init_synced"]                                 # from-scratch training starts from rank 0's weights on every rank
     # single-process references
     dev = torch.device("cuda", 0)
     cfg = P.reduced_config()
@@ -60,3 +62,7 @@ def test_two_ranks_match_single_process(tmp_path):
     tr.optimizer_step()
     big = tr.grads.cpu().abs() > 1e-3 * scale          # Adam's first step is sign-like: compare where the gradient is not rounding noise
     assert float((got["params1"] - tr.params.cpu())[big].abs().max()) <= 1e-6
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    run_two_ranks(tmp_path, "gloo")

@@ -241,6 +241,51 @@ def test_train_step_api_and_checkpoint_roundtrip(tmp_path):
     assert all(torch.equal(p.detach().cpu(), ema[k].cpu()) for k, p in d2.model.named_parameters())
 
 
+def test_resume_restores_adam_state(tmp_path):
+    """save -> --resume -> step equals the uninterrupted run (weights, EMA shadow, Adam moments, step count), and the
+    'optimizer' entry of the checkpoint is a torch.optim.Adam state_dict in the reference's parameter order (ddm_wavelet.py:186, :288)."""
+    from types import SimpleNamespace
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    cfg = P.reduced_config()
+    cfg.device = dev()
+    cfg.optim = SimpleNamespace(lr=1e-3, eps=1e-8, weight_decay=0.0)
+    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)
+    sd0 = P.procedural_state_dict(cfg, seed=61)
+    x0 = seeded((4, 96, 16, 16), 21).to(dev())
+    e, t = seeded((4, 3, 16, 16), 22).to(dev()), torch.tensor([900, 40, 510, 333])
+
+    def steps(tr, n):
+        for _ in range(n):
+            tr.loss_and_grads(x0, t, e)
+            tr.optimizer_step()
+
+    da = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
+    da.model.load_state_dict(sd0, strict=True)
+    ta = da.make_trainer(dtype="f32")
+    steps(ta, 12)                                               # the uninterrupted run
+    db = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
+    db.model.load_state_dict(sd0, strict=True)
+    tb = db.make_trainer(dtype="f32")
+    steps(tb, 10)
+    path = str(tmp_path / "resume.pth.tar")
+    tb.save_checkpoint(path, epoch=1)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    names = [k for k, _ in da.model.named_parameters()]
+    assert ck["optimizer"]["param_groups"][0]["params"] == list(range(len(names)))
+    assert tuple(ck["optimizer"]["state"][3]["exp_avg"].shape) == tuple(dict(da.model.named_parameters())[names[3]].shape)
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for _, p in da.model.named_parameters()], lr=1.0)
+    opt.load_state_dict(ck["optimizer"])                        # torch accepts it: the layout is torch.optim.Adam's own
+    assert float(opt.state_dict()["state"][0]["step"]) == 10 and opt.param_groups[0]["lr"] == 1e-3
+    args_r = SimpleNamespace(resume=path, sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)
+    dc = wavedm_amd.DenoisingDiffusion_Wavelet(args_r, cfg, generator=lambda x: x, dtype="f32")
+    tc = dc.make_trainer(dtype="f32")
+    assert tc.step == 10 and torch.equal(tc.exp_avg, tb.exp_avg) and torch.equal(tc.exp_avg_sq, tb.exp_avg_sq) and torch.equal(tc.ema, tb.ema)
+    steps(tc, 2)
+    assert tc.step == 12
+    assert torch.equal(tc.params, ta.params) and torch.equal(tc.ema, ta.ema)        # same kernels, same state: bit-identical
+
+
 def test_train_loop_on_synthetic_dataset(tmp_path):
     """DenoisingDiffusion_Wavelet.train(DATASET): RainDrop training loader (random crops) -> DWT -> train steps -> checkpoint at step 1."""
     import os

@@ -9,7 +9,9 @@ from conftest import rel_linf
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL = {"f32": 1e-3, "bf16": 6e-2}
+# f32 = the parity mode (north_star: 1e-3 max-norm-relative).  bf16 = the throughput mode: bounded at <= 2x what this suite measures on
+# the MI355X (printed by every test; 3.5e-3 ... 4.6e-3 on the full model, worst case 6.0e-3 on the reduced one), so a regression shows.
+TOL = {"f32": 1e-3, "bf16": 1e-2}
 
 
 def seeded(shape, seed):
@@ -89,12 +91,22 @@ def test_stitched_restore(golden, dtype):
     finally:
         torch.randn = real_randn
     assert int(s["n_corners"]) == 45
+    e = rel_linf(outs[0].cpu(), s["out"])
+    print(f"stitched restore {dtype}: rel_linf of the clamped output vs the reference's {e:.3e}")
     if dtype == "f32":
-        assert rel_linf(outs[0].cpu(), s["out"]) <= TOL[dtype]
+        assert e <= TOL[dtype]
     else:
-        # the output is clamped to [0,1] and mostly saturated (untrained weights): near the clamp a bf16-sized
-        # deviation flips a pixel, so bound the mean deviation instead of the max
-        assert float((outs[0].cpu() - torch.from_numpy(s["out"])).abs().mean()) <= 2e-2
+        # The clamped image is mostly saturated with untrained weights (a bf16-sized deviation flips pixels at the clamp), so the bf16
+        # bound is taken BEFORE the clamp: x0_preds[-5] in the wavelet domain against the oracle on the same inputs.
+        from oracle import wavedm_oracle as O
+        sd = P.procedural_state_dict(d.config)
+        _, _, x0_o = O.restore(sd, d.config, img, x_T.cpu(), 6, r=4)
+        xc = d.wavelet_dec(2 * img.cuda() - 1)
+        corners = O.grid_corners(30, 45, 16, 4)
+        _, x0 = d.sample_image(xc, x_T, x_other=xc[:, 3:].contiguous(), last=False, patch_locs=corners, patch_size=16, use_other=True)
+        e0 = rel_linf(x0[-5].cpu(), x0_o[-5])
+        print(f"stitched restore bf16: rel_linf of x0_preds[-5] before the clamp {e0:.3e}")
+        assert e0 <= TOL[dtype]
 
 
 def test_full_unet_forward_f32(golden):
@@ -123,6 +135,25 @@ def test_config0_sampler(golden, dtype):
     print(f"config0 {dtype}: rel_linf xs[-1] {e1:.3e}  x0[-5] {e2:.3e}")
     assert e1 <= TOL[dtype] and e2 <= TOL[dtype]
     assert torch.isfinite(out).all()
+
+
+def test_c1_length_bf16_tracks_f32():
+    """BASELINE.json configs[1] at its real length: 100 DDIM steps on the full-width model.  Four crops through the bf16 (throughput) path
+    against the f32 HIP path -- itself pinned to the reference at <= 1e-3 by test_config0_sampler / test_full_unet_forward_f32.  The
+    deviation of a 100-step trajectory is what the headline number's outputs carry; bound = 2x the measured 6e-3."""
+    from wavedm_amd import procedural as P
+    rainy, x_T = P.synthetic_batch(4, patch_px=256)
+    res = {}
+    for dtype in ("f32", "bf16"):
+        d, _ = make_diffusion(P.raindrop_wavelet_config(), dtype, 100)
+        out, xs_last, x0m5 = d.restore_batch(rainy.cuda(), x_T.cuda())
+        res[dtype] = (xs_last.cpu(), x0m5.cpu(), out.cpu())
+        del d
+        torch.cuda.empty_cache()
+    e1, e2 = rel_linf(res["bf16"][0], res["f32"][0]), rel_linf(res["bf16"][1], res["f32"][1])
+    print(f"C1 length (4 x 100 steps): bf16 vs f32 rel_linf xs[-1] {e1:.3e}  x0[-5] {e2:.3e}")
+    assert torch.isfinite(res["bf16"][2]).all()
+    assert e1 <= 1.2e-2 and e2 <= 1.2e-2
 
 
 def test_full_size_properties_bf16():
@@ -187,10 +218,18 @@ def test_config4_fullres_stitch(dtype):
     assert outs[0].shape == (1, 3, 480, 720)
     want, xs, x0 = O.restore(sd, cfg, img, x_T, 5, r=16)
     assert len(O.grid_corners(120, 180, 64, 16)) == 45
+    e = rel_linf(outs[0].cpu(), want)
+    print(f"config4 480x720 {dtype}: rel_linf of the clamped output {e:.3e}")
     if dtype == "f32":
-        assert rel_linf(outs[0].cpu(), want) <= 1e-3
+        assert e <= 1e-3
     else:
-        assert float((outs[0].cpu() - want).abs().mean()) <= 2e-2
+        # bf16: bound x0_preds[-5] before the clamp (see test_stitched_restore)
+        xc = d.wavelet_dec(2 * img.cuda() - 1)
+        _, x0g = d.sample_image(xc, x_T_dev, x_other=xc[:, 3:].contiguous(), last=False, patch_locs=O.grid_corners(120, 180, 64, 16), patch_size=64,
+                                use_other=True)
+        e0 = rel_linf(x0g[-5].cpu(), x0[-5])
+        print(f"config4 480x720 bf16: rel_linf of x0_preds[-5] before the clamp {e0:.3e}")
+        assert e0 <= TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

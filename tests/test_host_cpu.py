@@ -224,3 +224,19 @@ def test_config_file_matches_reference_yaml(golden):
         assert hashlib.sha256(json.dumps(d, sort_keys=True).encode()).hexdigest() == str(g["sha256"])
     ns = dict2namespace(shipped)
     assert ns.model.ch_mult == [1, 2, 4, 6] and ns.optim.lr == 4e-5 and ns.training.patch_n == 8 and ns.data.wavelet is True
+
+
+def test_parameter_order_is_the_references(golden):
+    """torch.optim state dicts index parameters by position (ddm_wavelet.py:186, :288), so `named_parameters()` must walk the tree in the
+    reference's order.  tests/golden/train.npz holds the reference's own `named_parameters()` key order for the reduced model."""
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    want = [str(k) for k in golden("train.npz")["grad_names"]]
+    m = wavedm_amd.DiffusionUNet(P.reduced_config(), dtype="f32")
+    assert [k for k, _ in m.named_parameters()] == want
+    # from-scratch initialisation follows nn.Conv2d / nn.Linear reset_parameters: biases are uniform(+-1/sqrt(fan_in)), not zero
+    sd = dict(m.named_parameters())
+    b = sd["down.0.block.0.conv1.bias"]
+    bound = 1.0 / (sd["down.0.block.0.conv1.weight"][0].numel() ** 0.5)
+    assert float(b.abs().max()) <= bound and float(b.abs().max()) > 0.0
+    assert float(sd["down.0.block.0.norm1.bias"].abs().max()) == 0.0 and float((sd["down.0.block.0.norm1.weight"] - 1).abs().max()) == 0.0

@@ -9,7 +9,9 @@ and the checkpoint dict format (`state_dict` with the reference's keys, optional
 `saved_models/raindrop/lastest.pth` (or `args.hfrm_ckpt`) when that file exists; the reference ships no such file
 (SURVEY.md §4), so without one the identity stand-in BASELINE.md §3 names is used and a warning says so.
 `generator=` overrides both: any callable, or "procedural" for an HFRM with seeded weights (tests, bench).
-Not rebuilt: training (`train`).
+Training (`train`, `train_step`, `make_trainer`) runs on `wavedm_amd.training.Trainer`: the reference's loop body
+with one flat-buffer gradient all-reduce in place of DistributedDataParallel; `--resume` restores weights, EMA shadow, Adam moments and
+the step count (ddm_wavelet.py:180-190).
 Deliberate differences: the model is NOT wrapped in DistributedDataParallel (inference needs no
 gradient all-reduce; `.model.module` is provided for callers that unwrap), outputs stay on the
 GPU (no per-step `.to('cpu')`), and the per-step statistics print is opt-in (`verbose=True`)."""
@@ -52,6 +54,7 @@ class DenoisingDiffusion_Wavelet(object):
         self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
         self.start_epoch, self.step = 0, 0
         self.ema_shadow = None
+        self.optimizer_state = None
 
         if os.path.isfile(getattr(args, "resume", "") or ""):
             self.load_ddm_ckpt(args.resume)
@@ -97,6 +100,7 @@ class DenoisingDiffusion_Wavelet(object):
         sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
         self.model.load_state_dict(sd, strict=True)
         self.ema_shadow = ckpt.get("ema_helper")
+        self.optimizer_state = ckpt.get("optimizer")                            # restored into the trainer (ddm_wavelet.py:186)
         if ema and self.ema_shadow is not None:                                # EMAHelper.ema, ddm_wavelet.py:55-60
             with torch.no_grad():
                 for name, p in self.model.named_parameters():
@@ -116,6 +120,11 @@ class DenoisingDiffusion_Wavelet(object):
                 if k in self.ema_shadow:
                     tr._view(tr.ema, k).copy_(self.ema_shadow[k].to(self.device))
         tr.step = self.step
+        osd = getattr(self, "optimizer_state", None)
+        if osd:                                                                 # --resume: Adam moments and step count (ddm_wavelet.py:186)
+            tr.load_optimizer_state_dict(osd)
+            tr.step = self.step = max(tr.step, self.step)
+        tr.broadcast_state(src=0)                                               # DDP's construction-time broadcast (ddm_wavelet.py:168)
         self.trainer = tr
         return tr
 

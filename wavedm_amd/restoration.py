@@ -75,7 +75,7 @@ class DiffusiveRestoration:
         H, W = x_output.shape[-2:]
         m_out = imageio.psnr_from_sums(imageio.sqdiff(gt, x_output), H, W)
         m_cond = imageio.psnr_from_sums(imageio.sqdiff(gt, inp), H, W)         # IDWT(DWT(x)) == x: the "cond" image is the input
-        m_hf = imageio.psnr_from_sums(imageio.sqdiff(gt, hf), H, W)
+        m_hf = imageio.psnr_from_sums(imageio.sqdiff(gt, hf.clamp(0.0, 1.0)), H, W)      # restoration.py:146 clamps x_output_wdnet first
         for k, name in enumerate(names):
             name = name[0] if isinstance(name, (list, tuple)) else name
             acc["torch"].append(m_out[k][0]); acc["y"].append(m_out[k][1]); acc["wdnet"].append(m_hf[k][1])
@@ -120,7 +120,7 @@ class DiffusiveRestoration:
         if acc["torch"]:
             print("psnr all torch", float(np.mean(acc["torch"])))
             print("psnr all np", float(np.mean(acc["y"])))
-            print("psnr all GPU", float(np.mean(acc["y"])))
+            print("psnr all GPU", float(np.mean(acc["y"])))       # deliberately the same accumulator: the reference's numpy and torch Y-PSNR agree
             print("psnr all wdnet", float(np.mean(acc["wdnet"])))
         self.last_outputs, self.last_psnrs, self.last_psnrs_y = outputs, acc["torch"], acc["y"]
         return outputs, acc["torch"]

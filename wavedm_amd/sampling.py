@@ -88,6 +88,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
     ncond, nother = x_cond.shape[1], (x_other.shape[1] if x_other is not None else 0)      # x_other None: model.use_other_channels False
     cin = unet.in_channels
     assert ncond + pc + nother == cin, f"channel split {ncond}+{pc}+{nother} != UNet in_channels {cin}"
+    if pc != 3:        # wdm_ddim_update / wdm_patch_accumulate / wdm_ddim_from_sums scatter exactly 3 prediction channels per patch
+        raise NotImplementedError(f"ddim_sample: model.pred_channels = {pc}; the DDIM update kernels are built for 3 (raindrop_wavelet.yml)")
     with torch.cuda.device(dev):
         if corners is None:
             p = H

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib, sampling
-from .unet import _make_config, resolve_dtype
+from .unet import _make_config, reference_param_order, resolve_dtype
 
 
 class Trainer:
@@ -34,6 +34,9 @@ class Trainer:
         self.betas, self.ema_mu = (float(betas[0]), float(betas[1])), float(ema_mu)
         if opt is not None and (getattr(opt, "optimizer", "Adam") != "Adam" or getattr(opt, "amsgrad", False)):
             raise NotImplementedError("wavedm_amd.Trainer implements optim.optimizer: Adam with amsgrad: False (utils/optimize.py:6-8, raindrop_wavelet.yml)")
+        if float(getattr(getattr(config, "model", None), "dropout", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("wavedm_amd.Trainer: model.dropout != 0 is not built (raindrop_wavelet.yml trains with dropout 0.0; "
+                                      "the backward pass in csrc/train_unet.hip has no dropout mask)")
         # training.use_mse (ddm_wavelet.py:263-266): back-propagate the x0-space loss instead of the noise-space one
         self.use_mse = bool(use_mse if use_mse is not None else getattr(getattr(config, "training", None), "use_mse", False))
         L = _lib.lib()
@@ -159,7 +162,66 @@ class Trainer:
         self.optimizer_step()
         return loss
 
+    # ---- optimizer state in torch.optim.Adam's state_dict layout (what the reference saves and restores, ddm_wavelet.py:186, :288) ---------
+    def param_order(self):
+        """Parameter names in the reference's `model.parameters()` order: torch.optim indexes its state by that position."""
+        return [k for k, _ in reference_param_order([(k, v[1]) for k, v in self.layout.items()]) if k in self.layout]
+
+    def optimizer_state_dict(self):
+        names = self.param_order()
+        state = {i: {"step": torch.tensor(float(self.step)), "exp_avg": self._view(self.exp_avg, k).detach().cpu().clone(),
+                     "exp_avg_sq": self._view(self.exp_avg_sq, k).detach().cpu().clone()} for i, k in enumerate(names)}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd):
+        """Accepts torch.optim.Adam.state_dict() (the reference's checkpoints and this trainer's) and this trainer's round-1 flat format."""
+        if not osd:
+            return False
+        if "state" in osd and "param_groups" in osd:
+            names = self.param_order()
+            st = osd["state"]
+            if len(st) == 0:
+                return False
+            if len(st) != len(names):
+                raise RuntimeError(f"optimizer state holds {len(st)} parameters, the model {len(names)}")
+            step = None
+            for i, k in enumerate(names):
+                e = st[i]
+                if tuple(e["exp_avg"].shape) != self.layout[k][1]:
+                    raise RuntimeError(f"optimizer state {i} has shape {tuple(e['exp_avg'].shape)}, parameter {k} {self.layout[k][1]}")
+                self._view(self.exp_avg, k).copy_(e["exp_avg"].to(self.device, torch.float32))
+                self._view(self.exp_avg_sq, k).copy_(e["exp_avg_sq"].to(self.device, torch.float32))
+                step = int(float(e["step"])) if step is None else step
+            g = osd["param_groups"][0]
+            self.lr, self.eps, self.weight_decay = float(g["lr"]), float(g["eps"]), float(g["weight_decay"])
+            self.betas = (float(g["betas"][0]), float(g["betas"][1]))
+            if g.get("amsgrad", False):
+                raise NotImplementedError("amsgrad optimizer state")
+            if step is not None:
+                self.step = step
+            return True
+        if "exp_avg" in osd and "exp_avg_sq" in osd:                # round-1 format of this repository: the two flat buffers
+            self.exp_avg.copy_(osd["exp_avg"].to(self.device))
+            self.exp_avg_sq.copy_(osd["exp_avg_sq"].to(self.device))
+            self.step = int(osd.get("step", self.step))
+            return True
+        raise RuntimeError("unrecognised optimizer state in the checkpoint")
+
     def save_checkpoint(self, path, epoch=0):
+        """The reference's checkpoint dict (ddm_wavelet.py:282-292): its own `load_ddm_ckpt` (:180-190) reads this file."""
         torch.save({"epoch": epoch, "step": self.step, "state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
-                    "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step, "lr": self.lr},
+                    "optimizer": self.optimizer_state_dict(),
                     "ema_helper": {k: v.cpu() for k, v in self.ema_state_dict().items()}, "params": None, "config": None}, path)
+
+    def broadcast_state(self, src=0, group=None):
+        """What DistributedDataParallel does at construction (ddm_wavelet.py:168): every rank starts from rank `src`'s parameters (and here
+        also its EMA shadow and Adam moments, so that a resumed run is identical on every rank)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for buf in (self.params, self.ema, self.exp_avg, self.exp_avg_sq):
+                dist.broadcast(buf, src=src, group=group)
+            st = torch.tensor([self.step], device=self.device, dtype=torch.int64)
+            dist.broadcast(st, src=src, group=group)
+            self.step = int(st.item())

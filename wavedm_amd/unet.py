@@ -56,6 +56,33 @@ def resolve_dtype(config=None, dtype=None):
     return _lib.DTYPES[name]
 
 
+def reference_param_order(table):
+    """[(key, shape), ...] in the library's order -> the reference's `named_parameters()` order (unet.py:81-105: norm1, conv1, temb_proj,
+    norm2, conv2, nin_shortcut; levels ascending).  torch.optim state dicts index parameters by position (ddm_wavelet.py:186, :288), so
+    the module tree and the trainer's optimizer state use this order.  The library lists the temb_proj layers last (they are one
+    concatenated matrix there) and the up path in execution order."""
+    temb = {k: s for k, s in table if ".temb_proj." in k}
+    ordered = []
+    for k, s in table:
+        if ".temb_proj." in k:
+            continue
+        ordered.append((k, s))
+        if k.endswith(".conv1.bias"):
+            blk = k[:-len(".conv1.bias")]
+            for leaf in ("weight", "bias"):
+                kk = f"{blk}.temb_proj.{leaf}"
+                if kk in temb:
+                    ordered.append((kk, temb.pop(kk)))
+    assert not temb, f"unplaced temb_proj parameters: {list(temb)[:3]}"
+    ups = [i for i, (k, _) in enumerate(ordered) if k.startswith("up.")]
+    if ups:
+        seg = ordered[ups[0]:ups[-1] + 1]
+        assert all(k.startswith("up.") for k, _ in seg)
+        seg.sort(key=lambda e: int(e[0].split(".")[1]))              # stable: up.0, up.1, ... each in its own order
+        ordered[ups[0]:ups[-1] + 1] = seg
+    return ordered
+
+
 class DiffusionUNet(nn.Module):
     def __init__(self, config, dtype=None):
         super().__init__()
@@ -85,10 +112,12 @@ class DiffusionUNet(nn.Module):
             self.wavelet_rec = WaveletTransform(scale=2, dec=False)
         self._names = []
         name, ndim, shape = C.c_char_p(), C.c_int(), (C.c_int64 * 4)()
+        table = []
         for i in range(L.wdm_unet_num_params(u)):
             _lib.check(L.wdm_unet_param_info(u, i, C.byref(name), C.byref(ndim), C.byref(shape)))
-            key = name.value.decode()
-            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            table.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value))))
+        ordered = reference_param_order(table)
+        for key, shp in ordered:
             self._names.append(key)
             self._register(key, shp)
         self._packed = None
@@ -111,14 +140,20 @@ class DiffusionUNet(nn.Module):
             node = node._modules[comp]
         p = torch.empty(shape, dtype=torch.float32)
         leaf = parts[-1]
-        if len(shape) > 1:                                      # conv / linear weight: torch's default init
+        # from-scratch initialisation = torch's reset_parameters of nn.Conv2d / nn.Linear (what the reference's modules get) and GroupNorm
+        if len(shape) > 1:                                      # conv / linear weight
             nn.init.kaiming_uniform_(p, a=math.sqrt(5))
-        elif leaf == "weight" and ("norm" in parts[-2]):        # GroupNorm gamma
-            p.fill_(1.0)
-        elif leaf == "weight":
-            p.fill_(1.0)
+            fan_in = 1
+            for v in shape[1:]:
+                fan_in *= v
+            self._last_fan_in = fan_in
+        elif "norm" in parts[-2]:                               # GroupNorm: gamma 1, beta 0
+            p.fill_(1.0) if leaf == "weight" else p.zero_()
+        elif leaf == "bias":                                    # uniform(+-1/sqrt(fan_in)) of the weight registered just before it
+            bound = 1.0 / math.sqrt(getattr(self, "_last_fan_in", 1))
+            nn.init.uniform_(p, -bound, bound)
         else:
-            p.zero_()
+            p.fill_(1.0)
         node.register_parameter(leaf, nn.Parameter(p))
 
     def __del__(self):
