@@ -40,7 +40,10 @@ enum {
     WDM_ENOTFOUND = -5  /* unknown parameter name */
 };
 
-enum { WDM_F32 = 0, WDM_BF16 = 1 };
+/* WDM_F32X3: fp32 tensors exactly as WDM_F32 (same buffers, same elementwise kernels); only the contractions differ -- each product is three
+ * bf16 MFMAs on operands split hi + lo in registers (~1e-5 end to end, several times the rate of the exact-fp32 MFMA chain).  UNet / block /
+ * conv entry points take it; the HFRM and the trainer take WDM_F32 or WDM_BF16. */
+enum { WDM_F32 = 0, WDM_BF16 = 1, WDM_F32X3 = 2 };
 
 typedef struct wdm_handle wdm_handle;
 typedef struct wdm_unet wdm_unet;
@@ -114,7 +117,7 @@ typedef struct wdm_unet_config {
     int out_ch;              /* 3 (12 / 48 with data.use_window / data.wavelet_in_unet) */
     int resolution;          /* data.image_size */
     int resamp_with_conv;    /* must be 1 */
-    int dtype;               /* WDM_BF16 (throughput) or WDM_F32 (parity mode) */
+    int dtype;               /* WDM_BF16 (throughput), WDM_F32 (exact parity mode) or WDM_F32X3 (fast parity mode) */
 } wdm_unet_config;
 
 int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out);

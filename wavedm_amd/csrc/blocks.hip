@@ -83,7 +83,7 @@ bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
 }
 
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
-    return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : launch_conv_f32(a, mode, s);
+    return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
 }
 
 // ---- one fused convolution ---------------------------------------------------------------------

@@ -179,6 +179,13 @@ __device__ __forceinline__ uint4 gn_silu_unit(const uint4& u, const float* sc, c
     return TI<T>::pack(f);
 }
 
+// "f32x3": fp32 tensors everywhere (same memory format and the same elementwise math as float), but every product of the contractions is
+// taken as three bf16 MFMAs on operands split hi + lo in registers: a*b ~ ah*bh + ah*bl + al*bh with fp32 accumulation.  hi = bf16(x)
+// (RNE), lo = bf16(x - hi) carry 16-17 mantissa bits of x, the dropped al*bl term is <= 2^-16 of the product: ~1e-5 end to end, inside
+// north_star's 1e-3, at several times the rate of the exact v_mfma_f32_16x16x4_f32 chain (which runs at the fp32 VALU rate).
+struct f32x3_t { float v; };
+template <> struct TI<f32x3_t> : TI<float> {};
+
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
 template <> __device__ __forceinline__ void mma16<__bf16>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -188,6 +195,26 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// A fragment unit holds 4 consecutive k (fp32) of a row: exactly the A / B layout of v_mfma_f32_16x16x16_bf16 (lane = row, k = 4 (lane >> 4) + 0..3)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16(const uint4& u, s16x4& hi, s16x4& lo) {
+    const float x0 = __uint_as_float(u.x), x1 = __uint_as_float(u.y), x2 = __uint_as_float(u.z), x3 = __uint_as_float(u.w);
+    const unsigned h01 = TI<__bf16>::pack2(x0, x1), h23 = TI<__bf16>::pack2(x2, x3);
+    const unsigned l01 = TI<__bf16>::pack2(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
+    const unsigned l23 = TI<__bf16>::pack2(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(s16x4, u32x2{h01, h23});
+    lo = __builtin_bit_cast(s16x4, u32x2{l01, l23});
+}
+template <> __device__ __forceinline__ void mma16<f32x3_t>(f32x4& acc, const uint4& a, const uint4& b) {
+    s16x4 ah, al, bh, bl;
+    split_bf16(a, ah, al);                       // inlined per (i, j): the compiler keeps one split per fragment (common subexpressions)
+    split_bf16(b, bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -772,5 +799,6 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 // host-side launchers implemented per dtype in conv_bf16.hip / conv_f32.hip
 int launch_conv_bf16(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32(const ConvArgs& a, int mode, hipStream_t s);
+int launch_conv_f32x3(const ConvArgs& a, int mode, hipStream_t s);
 
 }  // namespace wdm

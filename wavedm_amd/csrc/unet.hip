@@ -328,7 +328,7 @@ int wdm_destroy(wdm_handle* h) { delete h; return WDM_OK; }
 int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out) {
     if (!cfg || !out) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: null argument");   // h may be NULL for host-only layout queries
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad level count");
-    if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
+    if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32 && cfg->dtype != WDM_F32X3) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
     if (!cfg->resamp_with_conv) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resamp_with_conv=False is not supported");
     if (cfg->ch % 32 || cfg->in_channels < 1) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: ch must be a multiple of 32");
     if (cfg->resolution % (8 << (cfg->n_levels - 1))) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resolution %d too small for %d levels (coarsest level must be a multiple of 8)", cfg->resolution, cfg->n_levels);

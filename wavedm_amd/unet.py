@@ -6,7 +6,8 @@ libwavedm_hip.so.
   `load_state_dict(strict=True)`;
 * `forward(x, t)`: x (B, 96, R, R) fp32 NCHW on the GPU, t (n,) float with n in {1, B}
   -> (B, 3, R, R) fp32 NCHW, exactly the reference call;
-* compute dtype: `config.model.hip_dtype` / env WAVEDM_DTYPE in {"bf16" (default), "f32"}.
+* compute dtype: `config.model.hip_dtype` / env WAVEDM_DTYPE in {"bf16" (default: throughput), "f32" (exact-fp32 parity mode),
+  "f32x3" (fast parity mode: fp32 tensors, every product as three bf16 MFMAs on hi/lo-split operands)}.
   f32 is the parity mode (exact-fp32 MFMA), bf16 the throughput mode (bf16 MFMA, fp32 accumulate).
 
 The parameter tree is generated from the library's own parameter table (wdm_unet_param_info), so
@@ -52,7 +53,7 @@ def _make_config(config, dtype_code):
 def resolve_dtype(config=None, dtype=None):
     name = dtype or getattr(getattr(config, "model", None), "hip_dtype", None) or os.environ.get("WAVEDM_DTYPE", "bf16")
     if name not in _lib.DTYPES:
-        raise ValueError(f"unknown compute dtype {name!r} (use 'bf16' or 'f32')")
+        raise ValueError(f"unknown compute dtype {name!r} (use 'bf16', 'f32' or 'f32x3')")
     return _lib.DTYPES[name]
 
 
