@@ -178,14 +178,17 @@ def main():
         ach = dom["flops"] / dom["ms"] / 1e9
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
-            traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
+        traffic, traffic_src = None, None
+        for tag in ("r02", "r01"):
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", f"{tag}_traffic.json")))
+                traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
+                traffic_src = f"profiles/{tag}_traffic.json"
+                break
+            except Exception:
+                continue
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_traffic.json)",
+                    "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC passes, {traffic_src})",
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
