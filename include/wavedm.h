@@ -145,7 +145,7 @@ int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int 
 
 /* ---- per-block entry points (unit parity tests; same code the UNet executor runs) -----------
  * Weights are given in the reference layout as fp32 device pointers and packed on the fly into
- * `scratch`; x / y are NCHW f32 at this test boundary.  See wavedm_amd/csrc/blocks_api.hip. */
+ * `scratch`; x / y are NCHW f32 at this test boundary.  See wavedm_amd/csrc/api.hip. */
 typedef struct wdm_resblock_params {  /* ResnetBlock, models/unet.py:81-138 */
     int cin, cout;
     const float *norm1_w, *norm1_b, *conv1_w, *conv1_b, *temb_w, *temb_b;
@@ -172,6 +172,22 @@ int wdm_conv_forward(wdm_handle* h, const float* w, const float* b, int cin, int
 int wdm_temb_forward(wdm_handle* h, const float* t, int n_t, int ch, const float* w0, const float* b0,
                      const float* w1, const float* b1, float* temb_out, void* scratch, size_t scratch_bytes,
                      void* stream);
+
+/* ---- operators of the optional `data.global_attn` model (DiffusionUNet_Global / Attn_Global, models/unet.py:397-636) ----
+ * The ResnetBlocks, AttnBlocks and 3x3 / 1x1 convolutions of that model run on the block entry points above (wavedm_amd/unet_global.py);
+ * these are the operators only it has, as plain fp32 NCHW kernels (wavedm_amd/csrc/global_attn.hip).
+ * wdm_conv2d_direct: torch.nn.Conv2d(Cin, Cout, k, stride, pad, groups) (weight [Cout][Cin/groups][k][k]) or, transposed != 0,
+ *   torch.nn.ConvTranspose2d(Cin, Cout, k, stride, pad) (weight [Cin][Cout][k][k]) -- unet.py:407-424 (q, k, v), :522, :567.
+ * wdm_groupnorm: GroupNorm(32, eps) [+ SiLU] (unet.py:36-37; Attn_Global applies norm_patch to both inputs, :433-434).
+ * wdm_cross_attention: q (B,C,Nq), k and v (B,C,Nk <= 64) -> out (B,C,Nq), softmax(C^-0.5 q^T k) over the keys (unet.py:438-455).
+ * wdm_upsample_add: y = x + nearest_upsample(hp, scale) (unet.py:459-462). */
+int wdm_conv2d_direct(wdm_handle* h, const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, int k,
+                      int stride, int pad, int groups, int transposed, float* y, void* stream);
+int wdm_groupnorm(wdm_handle* h, const float* x, const float* gamma, const float* beta, int B, int C, int H, int W, float eps, int silu,
+                  float* y, void* stream);
+int wdm_cross_attention(wdm_handle* h, const float* q, const float* k, const float* v, int B, int C, int Nq, int Nk, float* out,
+                        void* stream);
+int wdm_upsample_add(wdm_handle* h, const float* x, const float* hp, int B, int C, int H, int W, int scale, float* y, void* stream);
 
 /* ---- HFRM -------------------------------------------------------------------
  * Replaces HFRM.__init__/forward, models/arch.py:206-253 (the module restoration.py:94 runs once per image to

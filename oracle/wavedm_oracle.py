@@ -210,6 +210,68 @@ def _unet_core(sd, config, x, t):
     return conv(sd, "conv_out", silu(group_norm(sd, "norm_out", h)), padding=1)
 
 
+def attn_global(sd, name, x_patch, x_global, local_patch=2):
+    """Attn_Global.forward, unet.py:432-462.  NOTE the reference normalises BOTH inputs with `norm_patch` (:433-434; `norm_global` is
+    registered but unused) and its k / v are depthwise 8x8 stride-8 convolutions of the whole-image map."""
+    h_ = group_norm(sd, name + ".norm_patch", x_patch)
+    hg = group_norm(sd, name + ".norm_patch", x_global)
+    c = x_patch.shape[1]
+    q = F.conv2d(h_, sd[name + ".q.weight"], sd[name + ".q.bias"], stride=local_patch)
+    gp = sd[name + ".k.weight"].shape[-1]
+    k = F.conv2d(hg, sd[name + ".k.weight"], sd[name + ".k.bias"], stride=gp, groups=c)
+    v = F.conv2d(hg, sd[name + ".v.weight"], sd[name + ".v.bias"], stride=gp, groups=c)
+    b, _, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = k.reshape(b, c, -1)
+    w_ = F.softmax(torch.bmm(q, k) * (int(c) ** (-0.5)), dim=2)
+    v = v.reshape(b, c, -1)
+    o = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    o = conv(sd, name + ".proj_out", o)
+    if local_patch > 1:
+        o = F.interpolate(o, scale_factor=float(local_patch), mode="nearest")
+    return x_patch + o
+
+
+def unet_global_forward(sd, config, x, t, x_global):
+    """DiffusionUNet_Global.forward, unet.py:585-636 -- including its quirk that the middle starts from `hs[-1]` (:612), i.e. the output
+    of the LAST level's global attention is discarded while the earlier levels' feed the next level."""
+    m = config.model
+    ch, ch_mult = m.ch, tuple(m.ch_mult)
+    nres, nrb, attn_res = len(ch_mult), m.num_res_blocks, list(m.attn_resolutions)
+    temb = linear(sd, "temb.dense.1", silu(linear(sd, "temb.dense.0", timestep_embedding(t, ch))))
+    res = config.data.image_size
+    hg = conv(sd, "global_conv_in", x_global, padding=1)
+    hs = [conv(sd, "conv_in", x, padding=1)]
+    h = hs[-1]
+    for l in range(nres):
+        for b in range(nrb):
+            h = resnet_block(sd, f"down.{l}.block.{b}", h, temb)
+            if res in attn_res:
+                h = attn_block(sd, f"down.{l}.attn.{b}", h)
+            hs.append(h)
+        if l != nres - 1:
+            h = downsample(sd, f"down.{l}.downsample", h)
+            hs.append(h)
+            res //= 2
+            hg = F.conv2d(hg, sd[f"down_global.{l}.conv.weight"], sd[f"down_global.{l}.conv.bias"], stride=2, padding=1)
+        h = attn_global(sd, f"down_global.{l}.attn", h, hg)
+    h = hs[-1]
+    h = resnet_block(sd, "mid.block_1", h, temb)
+    h = attn_block(sd, "mid.attn_1", h)
+    h = resnet_block(sd, "mid.block_2", h, temb)
+    for l in reversed(range(nres)):
+        for b in range(nrb + 1):
+            h = resnet_block(sd, f"up.{l}.block.{b}", torch.cat([h, hs.pop()], dim=1), temb)
+            if res in attn_res:
+                h = attn_block(sd, f"up.{l}.attn.{b}", h)
+        if l != 0:
+            h = upsample(sd, f"up.{l}.upsample", h)
+            res *= 2
+            hg = F.conv_transpose2d(hg, sd[f"up_global.{l}.conv.weight"], sd[f"up_global.{l}.conv.bias"], stride=2, padding=1)
+        h = attn_global(sd, f"up_global.{l}.attn", h, hg)
+    return conv(sd, "conv_out", silu(group_norm(sd, "norm_out", h)), padding=1)
+
+
 # ----------------------------------------------------------------------------------------------
 # a13-a16  schedule, grid, DDIM sampler       (reference: models/ddm_wavelet.py, utils/sampling.py)
 # ----------------------------------------------------------------------------------------------

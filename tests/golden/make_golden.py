@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--only-train", action="store_true", help="regenerate train.npz only")
     ap.add_argument("--only-variants", action="store_true", help="regenerate variants.npz only")
     ap.add_argument("--only-config", action="store_true", help="regenerate config.npz only")
+    ap.add_argument("--only-global", action="store_true", help="regenerate global.npz only")
     args = ap.parse_args()
 
     install_stubs()
@@ -250,6 +251,30 @@ def main():
             va[kind] = y.numpy()
         np.savez_compressed(out("variants.npz"), **va)
 
+    # ------------------------------------------------------------------ data.global_attn: DiffusionUNet_Global (models/unet.py:397-636)
+    def golden_global():
+        print("[global]")
+        c = P.global_config()
+        c.device = torch.device("cpu")
+        sd_g = P.procedural_global_state_dict(c, seed=61)
+        net_g = RU.DiffusionUNet_Global(c).eval()
+        assert list(net_g.state_dict().keys()) == list(sd_g.keys()), "parameter order / names of DiffusionUNet_Global"
+        assert [tuple(v.shape) for v in net_g.state_dict().values()] == [tuple(v.shape) for v in sd_g.values()]
+        net_g.load_state_dict(sd_g, strict=True)
+        x, xg, t = seeded((2, 6, 16, 16), 710), seeded((2, 3, 32, 32), 711), torch.tensor([400.0, 30.0])
+        y = net_g(x, t, xg)
+        check("unet global_attn", O.unet_global_forward(sd_g, c, x, t, xg), y)
+        ga = {"y": y.numpy(), "names": np.array(list(sd_g.keys()))}
+        # one Attn_Global on its own (32 channels, 16x16 patch map -> 64 queries, 32x32 whole-image map -> 16 key / value tokens)
+        ag = RU.Attn_Global(32).eval()
+        sd_a = {k[len("down_global.0.attn."):]: v for k, v in sd_g.items() if k.startswith("down_global.0.attn.")}
+        ag.load_state_dict(sd_a, strict=True)
+        xp, xq = seeded((2, 32, 16, 16), 712), seeded((2, 32, 32, 32), 713)
+        ya = ag(xp, xq)
+        check("Attn_Global", O.attn_global(sd_g, "down_global.0.attn", xp, xq), ya)
+        ga["attn"] = ya.numpy()
+        np.savez_compressed(out("global.npz"), **ga)
+
     # ------------------------------------------------------------------ config file (the YAML keys the drop-in must read)
     def golden_config():
         print("[config]")
@@ -269,6 +294,9 @@ def main():
 
     if args.only_config:
         golden_config()
+        return
+    if args.only_global:
+        golden_global()
         return
     if args.only_variants:
         golden_variants()

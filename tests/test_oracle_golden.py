@@ -212,3 +212,17 @@ def test_training_use_mse_matches_reference_golden(golden):
     for key in g.files:
         if key.startswith("gm:"):
             assert rel_linf(_sub(grads[key[3:]]), torch.from_numpy(g[key])) <= 1e-5, key
+
+
+def test_global_attn_model_matches_the_reference(golden):
+    """DiffusionUNet_Global / Attn_Global: the oracle's restatement against the reference's own outputs, and the parameter
+    table against the reference's state_dict order."""
+    from wavedm_amd import procedural as P
+    g = golden("global.npz")
+    cfg = P.global_config()
+    sd = P.procedural_global_state_dict(cfg, seed=61)
+    assert list(sd.keys()) == [str(k) for k in g["names"]]
+    x, xg, t = seeded((2, 6, 16, 16), 710), seeded((2, 3, 32, 32), 711), torch.tensor([400.0, 30.0])
+    assert rel_linf(O.unet_global_forward(sd, cfg, x, t, xg), g["y"]) <= 1e-6
+    xp, xq = seeded((2, 32, 16, 16), 712), seeded((2, 32, 32, 32), 713)
+    assert rel_linf(O.attn_global(sd, "down_global.0.attn", xp, xq), g["attn"]) <= 1e-6

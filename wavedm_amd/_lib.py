@@ -106,6 +106,10 @@ def lib():
         "wdm_trainer_set_objective": (i, [vp, i]),
         "wdm_trainer_step": (i, [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]),
         "wdm_trainer_adam_ema": (i, [vp, i64, f, f, f, f, f, f, vp]),
+        "wdm_conv2d_direct": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp, vp]),
+        "wdm_groupnorm": (i, [vp, vp, vp, vp, i, i, i, i, f, i, vp, vp]),
+        "wdm_cross_attention": (i, [vp, vp, vp, vp, i, i, i, i, vp, vp]),
+        "wdm_upsample_add": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
         "wdm_prof_enable": (i, [i]),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
@@ -126,7 +130,8 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
-            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_conv2d_direct", "wdm_groupnorm", "wdm_cross_attention", "wdm_upsample_add",
+            "wdm_prof_enable", "wdm_prof_report"]
 
 
 def prof_enable(on: bool):

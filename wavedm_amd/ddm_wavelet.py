@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from . import sampling
+from . import _lib, sampling
 from .unet import DiffusionUNet
 from .wavelet import WaveletTransform
 
@@ -49,9 +49,11 @@ class DenoisingDiffusion_Wavelet(object):
         self.wavelet_rec = WaveletTransform(scale=2, dec=False)
         self.generator = self._make_generator(generator, dtype)
 
-        if getattr(config.data, "global_attn", False):
-            raise NotImplementedError("data.global_attn=True (DiffusionUNet_Global) is outside the accelerated path")
-        self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
+        if getattr(config.data, "global_attn", False):                          # ddm_wavelet.py:149-152
+            from .unet_global import DiffusionUNet_Global
+            self.model = DiffusionUNet_Global(config, dtype=dtype).to(self.device)
+        else:
+            self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
         self.start_epoch, self.step = 0, 0
         self.ema_shadow = None
         self.optimizer_state = None
@@ -106,13 +108,16 @@ class DenoisingDiffusion_Wavelet(object):
                 for name, p in self.model.named_parameters():
                     if name in self.ema_shadow:
                         p.copy_(self.ema_shadow[name].to(p.device))
-        self.model.pack_weights(force=True)
+        if hasattr(self.model, "pack_weights"):
+            self.model.pack_weights(force=True)
         print("=> loaded checkpoint '{}' (epoch {}, step {})".format(load_path, self.start_epoch, self.step))
 
     # ---- training (ddm_wavelet.py:200-292) -----------------------------------------------------------------------
     def make_trainer(self, **kw):
         """The training state of this model on the HIP library (wavedm_amd.training.Trainer), initialised from the current weights."""
         from .training import Trainer
+        if getattr(self.config.data, "global_attn", False):
+            raise NotImplementedError("training the data.global_attn model is not built (inference only, wavedm_amd/unet_global.py)")
         tr = Trainer(self.config, device=self.device, dtype=kw.pop("dtype", None), **kw)
         tr.load_state_dict(self.model.state_dict())
         if self.ema_shadow is not None:
@@ -202,7 +207,7 @@ class DenoisingDiffusion_Wavelet(object):
         if eta != 0.:
             raise NotImplementedError("only eta = 0 (DDIM) is used by the reference (ddm_wavelet.py:303)")
         if use_global:
-            raise NotImplementedError("use_global=True is outside the accelerated path")
+            return self._ddim_overlapping_global(x, x_cond, list(seq), model, b, corners, p_size, total)
         if not use_other:
             x_other = None                                                      # ddm_wavelet.py:471-473: the UNet sees [x_cond | x_t] only
         if not self.config.data.begin_from_noise:                              # ddm_wavelet.py:445-447
@@ -217,6 +222,46 @@ class DenoisingDiffusion_Wavelet(object):
         if self.verbose:
             for i_t, x0, xn in zip(reversed(list(seq)), x0_preds, xs[1:]):
                 print(f"t:{i_t} x0 pred:{x0.mean().item()} x next:{xn.mean().item()}")
+        return xs, x0_preds
+
+    def _ddim_overlapping_global(self, x, x_cond, seq, model, b, corners, p_size, total):
+        """The `use_global` branch of generalized_steps_overlapping (ddm_wavelet.py:479-483): every patch is [x_cond crop | x_t crop] and the
+        model also sees the whole image `total`, repeated for each patch.  Crops and concatenation are tensor plumbing; the UNet and the
+        scatter-mean + DDIM update are library kernels (`wdm_ddim_update`, the one the main sampler uses)."""
+        if total is None:
+            raise ValueError("use_global=True needs `total`, the whole image the patches attend to")
+        if not self.config.data.begin_from_noise:
+            a = (1 - b).cumprod(dim=0)[self.num_timesteps - 1]
+            x = x_cond[:, :x.shape[1]] * a.sqrt() + x * (1.0 - a).sqrt()
+        x = _lib.require_cuda_f32(x, "x")
+        x_cond = _lib.require_cuda_f32(x_cond, "x_cond")
+        total = _lib.require_cuda_f32(total, "total")
+        nimg, pc, H, W = x.shape
+        if pc != 3:
+            raise NotImplementedError("the DDIM update kernels are built for 3 prediction channels")
+        p = int(p_size)
+        tri = [(im, int(hi), int(wi)) for im in range(nimg) for (hi, wi) in corners]
+        patches = torch.tensor(tri, dtype=torch.int32).to(self.device)
+        L, h = _lib.lib(), _lib.handle(self.device.index or 0)
+        abar = sampling.alpha_bar_table(b)
+        seq_next = [-1] + seq[:-1]
+        xs, x0_preds, xt = [x], [], x
+        cond_p = torch.cat([x_cond[im:im + 1, :, hi:hi + p, wi:wi + p] for (im, hi, wi) in tri], dim=0)
+        tot_p = torch.cat([total[im:im + 1] if total.shape[0] == nimg else total[:1] for (im, _, _) in tri], dim=0).contiguous()
+        with torch.cuda.device(self.device):
+            for i_t, j_t in zip(reversed(seq), reversed(seq_next)):
+                at, at_next = abar[i_t + 1], abar[j_t + 1]
+                xt_p = torch.cat([xt[im:im + 1, :, hi:hi + p, wi:wi + p] for (im, hi, wi) in tri], dim=0)
+                inp = torch.cat([cond_p, xt_p], dim=1).contiguous()
+                t = torch.tensor([float(i_t)], device=self.device)
+                eps = torch.cat([model(inp[i:i + 8], t, tot_p[i:i + 8]) for i in range(0, len(tri), 8)], dim=0).contiguous()      # manual_batching_size 8
+                x0, xn = torch.empty_like(xt), torch.empty_like(xt)
+                _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), _lib.ptr(patches), len(tri), p, _lib.ptr(xt), nimg, H, W, float((1 - at).sqrt()),
+                                             float(at.sqrt()), float(at_next.sqrt()), float((1 - at_next).sqrt()), _lib.ptr(x0), _lib.ptr(xn),
+                                             _lib.stream_ptr()))
+                x0_preds.append(x0)
+                xs.append(xn)
+                xt = xn
         return xs, x0_preds
 
     def overlapping_grid_indices(self, x_cond, output_size, r=None):

@@ -186,6 +186,88 @@ def unet_param_shapes(config) -> "OrderedDict[str, tuple]":
     return shapes
 
 
+def unet_global_param_shapes(config) -> "OrderedDict[str, tuple]":
+    """Ordered {state_dict key: shape} of `DiffusionUNet_Global` (models/unet.py:463-583) in the reference's registration order: temb,
+    conv_in, down, global_conv_in, down_global, mid, up, up_global, norm_out, conv_out.  Its input is [x_cond | x_t] (2 x in_channels when
+    data.conditional, :473) plus the whole image `x_global` with model.in_channels channels (:506)."""
+    m = config.model
+    ch, ch_mult = m.ch, tuple(m.ch_mult)
+    nres = len(ch_mult)
+    in_ch_mult = (1,) + ch_mult
+    base = OrderedDict(unet_param_shapes(_global_base_config(config)))
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def take(prefix):
+        for k in [k for k in base if k.startswith(prefix)]:
+            out[k] = base.pop(k)
+
+    def conv(name, cin, cout, k, transposed=False, depthwise=False):
+        out[name + ".weight"] = (cin, cout, k, k) if transposed else ((cout, 1, k, k) if depthwise else (cout, cin, k, k))
+        out[name + ".bias"] = (cout,)
+
+    def attn_global(name, c, lp=2, gp=8):
+        for n in ("norm_patch", "norm_global"):
+            out[f"{name}.{n}.weight"] = (c,)
+            out[f"{name}.{n}.bias"] = (c,)
+        conv(name + ".q", c, c, lp)
+        conv(name + ".k", c, c, gp, depthwise=True)
+        conv(name + ".v", c, c, gp, depthwise=True)
+        conv(name + ".proj_out", c, c, 1)
+
+    take("temb.")
+    take("conv_in.")
+    take("down.")
+    conv("global_conv_in", m.in_channels, ch, 3)
+    for l in range(nres):
+        block_in, block_out = ch * in_ch_mult[l], ch * ch_mult[l]
+        if l != nres - 1:
+            conv(f"down_global.{l}.conv", block_in, block_out, 4)
+        attn_global(f"down_global.{l}.attn", block_out)
+    take("mid.")
+    take("up.")
+    block_in = ch * ch_mult[-1]
+    ups = {}
+    for l in reversed(range(nres)):
+        block_out = ch * ch_mult[l]
+        saved, out = out, OrderedDict()
+        if l != 0:
+            conv(f"up_global.{l}.conv", block_in, block_out, 4, transposed=True)
+        attn_global(f"up_global.{l}.attn", block_out)
+        ups[l], out = out, saved
+        block_in = block_out
+    for l in range(nres):                      # `self.up_global.insert(0, ...)`: state_dict order is up_global.0, up_global.1, ...
+        out.update(ups[l])
+    take("norm_out.")
+    take("conv_out.")
+    assert not base, list(base)[:3]
+    return out
+
+
+def _global_base_config(config):
+    """The plain-UNet view of a global_attn config: same trunk, input = 2 x in_channels (conditional) and no `other` channels."""
+    import copy
+    c = copy.deepcopy(config)
+    c.model.use_other_channels = False
+    c.model.pred_channels = c.model.in_channels if getattr(c.data, "conditional", True) else 0
+    return c
+
+
+def global_config():
+    """Reduced `data.global_attn: True` fixture: 16x16 patches with a 32x32 whole-image map (2x2 = 4 key / value tokens on the way down,
+    4x4 = 16 on the way up).  ch_mult = (1, 1): the reference's DiffusionUNet_Global only runs when the last level keeps the channel count
+    (its last `down_global.attn` normalises the un-convolved whole-image map with the last level's GroupNorm, unet.py:609-610)."""
+    c = raindrop_wavelet_config(image_size=16, ch=32, ch_mult=(1, 1), attn_resolutions=(8,))
+    c.data.global_attn = True
+    c.model.use_other_channels = False
+    c.model.in_channels, c.model.pred_channels, c.model.out_ch = 3, 3, 3
+    return c
+
+
+def procedural_global_state_dict(config, seed: int = 61):
+    import torch
+    return OrderedDict((k, torch.from_numpy(procedural_tensor(k, s, seed))) for k, s in unet_global_param_shapes(config).items())
+
+
 # ----------------------------------------------------------------------------------------------
 # procedural values
 # ----------------------------------------------------------------------------------------------

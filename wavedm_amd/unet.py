@@ -89,7 +89,7 @@ class DiffusionUNet(nn.Module):
         super().__init__()
         d = config.data
         if getattr(d, "global_attn", False):
-            raise NotImplementedError("data.global_attn (DiffusionUNet_Global, unet.py:397-636) is not built (SURVEY.md §8f-4)")
+            raise ValueError("data.global_attn: True selects wavedm_amd.DiffusionUNet_Global (unet.py:397-636), not DiffusionUNet")
         self.config = config
         # optional input / output re-arrangements around the same network (unet.py:309-350, :387-391), off in raindrop_wavelet.yml
         self.use_window = bool(getattr(d, "use_window", False))
