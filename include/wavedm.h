@@ -61,6 +61,14 @@ int wdm_destroy(wdm_handle* h);
  * H and W must be multiples of 4. */
 int wdm_dwt_fwd(wdm_handle* h, const float* x, float* y, int B, int H, int W, void* stream);
 int wdm_dwt_inv(wdm_handle* h, const float* y, float* x, int B, int hh, int ww, void* stream);
+/* The same transforms with the element-wise steps the reference runs around them folded in (no extra pass, no ATen kernel in the loop):
+ *   wdm_dwt_fwd_affine:   y = DWT(scale * x + shift)            -- data_transform, 2x - 1 (restoration.py:8-9, ddm_wavelet.py:345-348)
+ *   wdm_dwt_inv_compose:  coefficient channels [0, n_lo) are read from y_lo (B, lo_channels, h, w), the others from y_hi (B,48,h,w) -- the
+ *                         torch.cat([x0[:, :pc], hf_wav[:, pc:]]) of restoration.py:114 -- and, if to_unit_range, the output is
+ *                         clamp((x + 1) / 2, 0, 1) = inverse_data_transform (restoration.py:12-13).  n_lo = 0: y_lo may be NULL. */
+int wdm_dwt_fwd_affine(wdm_handle* h, const float* x, float scale, float shift, float* y, int B, int H, int W, void* stream);
+int wdm_dwt_inv_compose(wdm_handle* h, const float* y_lo, int lo_channels, int n_lo, const float* y_hi, float* x, int B, int hh, int ww,
+                        int to_unit_range, void* stream);
 
 /* ---- layout helpers at the UNet boundary ---------------------------------------------------
  * A "patch list" is n triples (img, hi, wi) of int32 on the DEVICE: patch k is the p x p window

@@ -47,6 +47,15 @@ int wdm_dwt_inv(wdm_handle* h, const float* y, float* x, int B, int hh, int ww, 
     if (!h || !x || !y) WDM_FAIL(WDM_EINVAL, "wdm_dwt_inv: null argument");
     return k_dwt_inv(y, x, B, hh, ww, (hipStream_t)stream);
 }
+int wdm_dwt_fwd_affine(wdm_handle* h, const float* x, float scale, float shift, float* y, int B, int H, int W, void* stream) {
+    if (!h || !x || !y) WDM_FAIL(WDM_EINVAL, "wdm_dwt_fwd_affine: null argument");
+    return k_dwt_fwd(x, y, B, H, W, (hipStream_t)stream, scale, shift);
+}
+int wdm_dwt_inv_compose(wdm_handle* h, const float* y_lo, int lo_channels, int n_lo, const float* y_hi, float* x, int B, int hh, int ww, int to_unit_range,
+                        void* stream) {
+    if (!h || !x || !y_hi) WDM_FAIL(WDM_EINVAL, "wdm_dwt_inv_compose: null argument");
+    return k_dwt_inv(y_hi, x, B, hh, ww, (hipStream_t)stream, y_lo, lo_channels, n_lo, to_unit_range);
+}
 int wdm_pack_channels(wdm_handle* h, const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96, int c_total, int c_off,
                       int dtype, void* stream) {
     if (!h || !src || !x96) WDM_FAIL(WDM_EINVAL, "wdm_pack_channels: null argument");

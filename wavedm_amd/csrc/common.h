@@ -106,8 +106,8 @@ inline size_t conv_packed_bytes(int cin, int cout, int k, int dtype) {
 }
 
 // ---- kernels (elementwise.hip) ---------------------------------------------------------------
-int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s);
-int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s);
+int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s, float scale = 1.0f, float shift = 0.0f);      // DWT(scale * x + shift)
+int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s, const float* y_lo = nullptr, int lo_total = 0, int n_lo = 0, int post = 0);
 int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96,
                     int c_total, int c_off, int dtype, hipStream_t s);
 int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W,

@@ -30,7 +30,8 @@ __device__ __forceinline__ void wht16(float* v) {
     for (int i = 0; i < 16; ++i) v[i] *= 0.25f;
 }
 
-__global__ __launch_bounds__(256) void dwt_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W) {
+// pre-affine: the transform of (scale * x + shift) -- data_transform (2x - 1, restoration.py:8-9) folded into the load
+__global__ __launch_bounds__(256) void dwt_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, float scale, float shift) {
     const int h = H >> 2, w = W >> 2;
     const long long total = (long long)B * 3 * h * w;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float4 r = *(const float4*)(src + (long long)p * W);
-            const float rq[4] = {r.x, r.y, r.z, r.w};
+            const float rq[4] = {r.x * scale + shift, r.y * scale + shift, r.z * scale + shift, r.w * scale + shift};
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[((p & 1) << 3) | ((q & 1) << 2) | ((p >> 1) << 1) | (q >> 1)] = rq[q];
         }
@@ -53,7 +54,11 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void dwt_inv_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int h, int w) {
+// Coefficient channel ch = j*3 + c comes from y_lo (B, lo_total, h, w) when ch < n_lo, else from y (B, 48, h, w): the
+// torch.cat([x0[:, :pc], hf_wav[:, pc:]]) of restoration.py:114 without materialising it (n_lo = 0: plain inverse).
+// post != 0: clamp((x + 1) / 2, 0, 1) = inverse_data_transform (restoration.py:12-13) on the way out.
+__global__ __launch_bounds__(256) void dwt_inv_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int h, int w, const float* __restrict__ y_lo,
+                                                      int lo_total, int n_lo, int post) {
     const int H = h << 2, W = w << 2;
     const long long total = (long long)B * 3 * h * w;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
@@ -63,8 +68,15 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(const float* __restrict__ 
         const int b = (int)(id / ((long long)w * h * 3));
         float t[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = y[(((long long)b * 48 + j * 3 + c) * h + u) * w + v];
+        for (int j = 0; j < 16; ++j) {
+            const int chn = j * 3 + c;
+            t[j] = chn < n_lo ? y_lo[(((long long)b * lo_total + chn) * h + u) * w + v] : y[(((long long)b * 48 + chn) * h + u) * w + v];
+        }
         wht16(t);   // the basis is orthonormal and symmetric in (j, idx): the inverse is the same butterfly
+        if (post) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = fminf(fmaxf((t[i] + 1.0f) * 0.5f, 0.0f), 1.0f);
+        }
         float* dst = x + (((long long)b * 3 + c) * H + 4 * u) * W + 4 * v;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -76,17 +88,18 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(const float* __restrict__ 
     }
 }
 
-int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s) {
+int k_dwt_fwd(const float* x, float* y, int B, int H, int W, hipStream_t s, float scale, float shift) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3)) WDM_FAIL(WDM_EINVAL, "dwt_fwd: H=%d W=%d must be positive multiples of 4", H, W);
     const long long total = (long long)B * 3 * (H / 4) * (W / 4);
-    hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, x, y, B, H, W);
+    hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, x, y, B, H, W, scale, shift);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
-int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s) {
+int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s, const float* y_lo, int lo_total, int n_lo, int post) {
     if (B <= 0 || h <= 0 || w <= 0) WDM_FAIL(WDM_EINVAL, "dwt_inv: bad shape");
+    if (n_lo < 0 || n_lo > 48 || (n_lo > 0 && (!y_lo || lo_total < n_lo))) WDM_FAIL(WDM_EINVAL, "dwt_inv: bad low-band source (%d of %d channels)", n_lo, lo_total);
     const long long total = (long long)B * 3 * h * w;
-    hipLaunchKernelGGL(dwt_inv_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, y, x, B, h, w);
+    hipLaunchKernelGGL(dwt_inv_kernel, dim3(nblocks(total, 256) > 8192 ? 8192 : nblocks(total, 256)), dim3(256), 0, s, y, x, B, h, w, y_lo, lo_total, n_lo, post);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -331,13 +344,25 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
     const int n0c = max(0, min(C0 - cg0, gw));        // channels of this group that live in tensor 0
     const int items0 = n0c * nslab0, items = items0 + (gw - n0c) * nslab1;
-    for (int it = lane; it < items; it += 64) {
-        float4 v;
-        if (it < items0) { const int ci = it / nslab0, sl = it % nslab0; v = st0[((long long)b * nslab0 + sl) * C0 + cg0 + ci]; }
-        else { const int j = it - items0; const int ci = n0c + j / nslab1, sl = j % nslab1; v = st1[((long long)b * nslab1 + sl) * C1 + (cg0 + ci - C0)]; }
+    // Up to four partials per lane, all loaded before any is used: the kernel is one wave per (group, image) and its time is the
+    // dependent-load latency of this loop (rocprofv3: 5.5 us average with one load in flight per lane).  The accumulation order per lane
+    // (ascending item index) and the shuffle tree are unchanged, so the result is bit-identical.
+    auto load_item = [&](int it) __attribute__((always_inline)) -> float4 {
+        if (it < items0) { const int ci = it / nslab0, sl = it % nslab0; return st0[((long long)b * nslab0 + sl) * C0 + cg0 + ci]; }
+        const int j = it - items0; const int ci = n0c + j / nslab1, sl = j % nslab1;
+        return st1[((long long)b * nslab1 + sl) * C1 + (cg0 + ci - C0)];
+    };
+    auto accumulate = [&](const float4& v) __attribute__((always_inline)) {
         const double n = (double)v.w, d = (double)v.x - kg, a1 = (double)v.y, a2 = (double)v.z;
         S1 += a1 + n * d;
         S2 += a2 + 2.0 * d * a1 + n * d * d;
+    };
+    for (int it0 = lane; it0 < items; it0 += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < items) v[u] = load_item(it0 + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < items) accumulate(v[u]);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {

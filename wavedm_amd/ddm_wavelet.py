@@ -324,9 +324,9 @@ class DenoisingDiffusion_Wavelet(object):
 
         rainy01 (B,3,4R,4R) in [0,1]; x_T (B,3,R,R) start noise; returns the restored (B,3,4R,4R) in [0,1] built
         from x0_preds[keep] like restoration.py:108-134, plus (xs[-1], x0_preds[keep])."""
-        x_cond = self.wavelet_dec(data_transform(rainy01))
+        x_cond = self.wavelet_dec.forward_affine(rainy01)                        # DWT(2x - 1): data_transform folded into the kernel
         hf = self.generator(rainy01) if hfrm_out01 is None else hfrm_out01
-        hf_wav = self.wavelet_dec(data_transform(hf))
+        hf_wav = x_cond if hf is rainy01 else self.wavelet_dec.forward_affine(hf)   # identity stand-in: the same tensor, not a second pass
         ob = self.config.model.other_channels_begin
         x_other = hf_wav[:, ob:].contiguous()
         skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
@@ -336,5 +336,5 @@ class DenoisingDiffusion_Wavelet(object):
                                             stop_at=keep if early_stop else None)      # early_stop: skip the discarded tail
         pc = self.config.model.pred_channels
         x0 = x0_preds[keep]
-        out = torch.cat([x0[:, :pc], hf_wav[:, pc:]], dim=1)
-        return inverse_data_transform(self.wavelet_rec(out)), (xs[-1] if xs[-1] is not None else xs[len(seq) + keep + 1]), x0
+        out = self.wavelet_rec.compose(x0, hf_wav, pc)                            # IDWT of [x0 low bands | HFRM bands], clamp((x + 1) / 2) on the way out
+        return out, (xs[-1] if xs[-1] is not None else xs[len(seq) + keep + 1]), x0

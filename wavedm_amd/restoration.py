@@ -60,17 +60,16 @@ class DiffusiveRestoration:
         pc, ob = cfg.model.pred_channels, cfg.model.other_channels_begin
         x = torch.cat([it[0] for it in items], dim=0).to(d.device, non_blocking=True).float().contiguous()
         names = [it[1] for it in items]
-        x_all = data_transform(x)
         inp, gt = x[:, :3].contiguous(), x[:, 3:].contiguous()
-        x_cond = d.wavelet_dec(x_all[:, :3].contiguous())                      # restoration.py:88
-        x_gt = d.wavelet_dec(x_all[:, 3:].contiguous())                        # :89
+        x_cond = d.wavelet_dec.forward_affine(inp)                             # restoration.py:79, :88: DWT(2x - 1) in one kernel
+        x_gt = d.wavelet_dec.forward_affine(gt)                                # :89
         hf = d.generator(inp)                                                  # :94 (HFRM)
-        hf_wav = d.wavelet_dec(data_transform(hf).contiguous())                # :95-96
+        hf_wav = d.wavelet_dec.forward_affine(hf.contiguous())                 # :95-96
         x_other = hf_wav[:, ob:].contiguous()                                  # :102
         xs, x0_preds = self.diffusive_restoration(x_cond, x_other=x_other, r=r, last=False, total=None,
                                                   use_global=False, use_other=True)
         pred = x0_preds[-5]                                                    # :108
-        rec = lambda lo, hi: inverse_data_transform(d.wavelet_rec(torch.cat([lo[:, :pc], hi[:, pc:]], dim=1).contiguous()))
+        rec = lambda lo, hi: d.wavelet_rec.compose(lo, hi, pc)                    # IDWT(cat([lo[:, :pc], hi[:, pc:]])) -> clamp((x + 1) / 2), one kernel
         x_output = rec(pred, hf_wav)                                           # :114-115, :124, :134
         H, W = x_output.shape[-2:]
         m_out = imageio.psnr_from_sums(imageio.sqdiff(gt, x_output), H, W)

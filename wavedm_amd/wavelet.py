@@ -41,6 +41,35 @@ class WaveletTransform(nn.Module):
         self.scale, self.dec, self.transpose = scale, dec, transpose
         self.conv = _FrozenConv()
 
+    def forward_affine(self, x, scale=2.0, shift=-1.0):
+        """dec only: DWT(scale * x + shift) in one kernel -- `wavelet_dec(data_transform(x))` of the reference (restoration.py:88-96)."""
+        assert self.dec
+        x = _lib.require_cuda_f32(x, "WaveletTransform input")
+        B, C, H, W = x.shape
+        if C != 3 or H % 4 or W % 4:
+            raise ValueError(f"WaveletTransform(dec): expected (B,3,4h,4w), got {tuple(x.shape)}")
+        y = torch.empty(B, 48, H // 4, W // 4, device=x.device, dtype=torch.float32)
+        if B:
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().wdm_dwt_fwd_affine(_lib.handle(x.device.index or 0), _lib.ptr(x), float(scale), float(shift), _lib.ptr(y), B, H, W,
+                                                         _lib.stream_ptr()))
+        return y
+
+    def compose(self, lo, hi, n_lo, to_unit_range=True):
+        """rec only: IDWT(cat([lo[:, :n_lo], hi[:, n_lo:]])) [then clamp((x + 1) / 2, 0, 1)] in one kernel -- restoration.py:114-134."""
+        assert not self.dec
+        hi = _lib.require_cuda_f32(hi, "WaveletTransform hi")
+        lo = _lib.require_cuda_f32(lo, "WaveletTransform lo")
+        B, C, hh, ww = hi.shape
+        if C != 48 or lo.shape[0] != B or tuple(lo.shape[2:]) != (hh, ww) or not (0 <= n_lo <= min(48, lo.shape[1])):
+            raise ValueError(f"WaveletTransform.compose: lo {tuple(lo.shape)} / hi {tuple(hi.shape)} / n_lo {n_lo}")
+        y = torch.empty(B, 3, hh * 4, ww * 4, device=hi.device, dtype=torch.float32)
+        if B:
+            with torch.cuda.device(hi.device):
+                _lib.check(_lib.lib().wdm_dwt_inv_compose(_lib.handle(hi.device.index or 0), _lib.ptr(lo), lo.shape[1], int(n_lo), _lib.ptr(hi), _lib.ptr(y),
+                                                          B, hh, ww, 1 if to_unit_range else 0, _lib.stream_ptr()))
+        return y
+
     def forward(self, x):
         x = _lib.require_cuda_f32(x, "WaveletTransform input")
         L, h = _lib.lib(), _lib.handle(x.device.index or 0)
