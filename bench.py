@@ -143,10 +143,12 @@ def main():
     elapsed = time.perf_counter() - t1
     rank_elapsed = None
     if world > 1:
-        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(every, torch.tensor([elapsed], device=dev, dtype=torch.float64))
-        rank_elapsed = [float(v.item()) for v in every]
-        elapsed = max(rank_elapsed)                                      # the job is as slow as its slowest rank
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmin = tmax.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_elapsed = [float(tmin.item()), float(tmax.item())]
+        elapsed = rank_elapsed[1]                                        # the job is as slow as its slowest rank
         gathered = parallel.all_gather_shards(out, B * world)          # outside the timed region
         assert gathered.shape[0] == B * world
     finite = bool(torch.isfinite(out).all())
