@@ -1,0 +1,43 @@
+// Launcher of the fused attention core (attn_fused_kernel.h).
+#include <atomic>
+
+#include "common.h"
+#include "attn_fused_kernel.h"
+
+namespace wdm {
+
+bool attn_fused_eligible(int dtype, int N, int C) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("WDM_ATTN_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }      // WDM_ATTN_FUSED=0: the three-launch form (A/B runs)
+    return on && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C;
+}
+
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s) {
+    using Cf = AttnFusedCfg;
+    if (!qk || !vT || !o || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
+    const double qkb = (double)B * Cf::N * 2.0 * C * 2.0, vtb = (double)B * C * Cf::N * 2.0;
+    if (qkb >= 4294901760.0) WDM_FAIL(WDM_EINVAL, "attn(fused): q|k tensor exceeds the 4 GB buffer-offset range");
+    AttnFusedArgs a{};
+    a.qk = qk; a.vT = vT; a.o = o; a.B = B; a.C = C;
+    a.alpha = (float)std::pow((double)C, -0.5);
+    a.qk_bytes = (unsigned)qkb; a.vt_bytes = (unsigned)vtb;
+    static std::atomic<unsigned> devs{0};
+    int dev = 0;
+    WDM_HIP(hipGetDevice(&dev));
+    if (!(devs.load() & (1u << (dev & 31)))) {
+        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
+        devs.fetch_or(1u << (dev & 31));
+    }
+    const bool prof = prof_enabled();
+    if (prof) {
+        char name[96];
+        snprintf(name, sizeof(name), "attn_fused_n256_bf16|16x16 C=%d", C);
+        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C, (double)B * Cf::N * C * 2.0 * 4.0);
+    }
+    hipLaunchKernelGGL(attn_fused_kernel, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a);      // 8 images x 4 query blocks per group of 32
+    if (prof) prof_end(s);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+}  // namespace wdm

@@ -1,0 +1,258 @@
+// Fused single-head self-attention core for the 16 x 16 maps (N = 256 tokens, C = 64 ... 512 channels), bf16:
+//     O[b][i][c] = sum_j softmax_j(C^-1/2 q[b][i] . k[b][j]) v[b][j][c]                                     (models/unet.py:176-189)
+// in ONE kernel instead of Q.K^T (GEMM, fp32 S to HBM) -> softmax_rows (S -> P) -> P.V (GEMM): S and P never leave the CU.
+//
+// Workgroup = (image, block of 64 queries), 8 waves.  Operands come in the layouts the projection GEMMs already produce:
+//   qk  [B][256][2C]   token-major, q in columns [0, C), k in [C, 2C)     (the fused q|k 1x1 conv)
+//   vT  [B][C][256]    channel-major                                       (the v 1x1 conv, stored through Y_NCHW)
+//   o   [B][256][C]    token-major (input of proj_out)
+//
+// Phase 1   S^T[key][query] = K . Q^T over the C channels in steps of 64: both operands are [row][channel] images (128-byte rows, 16-byte
+//           unit u of row r in slot u ^ ((r >> 1) & 7), as conv_gemm_kernel.h), staged by LDS-DMA through a ring of three 40 KB stages
+//           (256 key rows + 64 query rows), two stages in flight, counted vmcnt, one raw barrier per step.  Waves = 4 (key blocks of 64) x 2
+//           (query blocks of 32).  Computing the TRANSPOSE puts, in every lane, four consecutive KEYS of one query: the softmax statistics of a
+//           query reduce over registers, then over the four lane quarters (xor 16 / 32 shuffles), then over the four key-block waves through
+//           256 floats of LDS; and P goes to LDS as 8-byte pieces of a [query][key] image -- the A/B-operand layout of phase 2.
+// Softmax   max and sum per query in fp32 (exp2 of the log2(e)-scaled scores), P = bf16(e / sum).
+// Phase 2   O^T[channel][query] = V^T . P^T over the 256 keys in steps of 32: V^T rows are channels ([row][key] image, 64-byte rows in the conv
+//           kernel's rotated layout), P rows are queries (512-byte rows, unit slot ^ (row & 15)); ring of three 32 KB V^T chunks.  Waves = 8
+//           channel blocks of C / 8.  The transpose again leaves four consecutive CHANNELS of a query in a lane: 8-byte global stores.
+// The first V^T chunks are fetched while the softmax runs.  LDS: phase 1 3 x 40 KB; phase 2 P 32 KB + 3 x 32 KB; + 1 KB of statistics.
+#pragma once
+#include "conv_kernel.h"
+
+namespace wdm {
+
+struct AttnFusedArgs {
+    const void* qk;      // [B][256][2C] bf16
+    const void* vT;      // [B][C][256] bf16
+    void* o;             // [B][256][C] bf16
+    int B, C;
+    float alpha;         // C^-1/2
+    unsigned qk_bytes, vt_bytes;
+};
+
+struct AttnFusedCfg {
+    static constexpr int N = 256, QB = 64, NTHREADS = 512;
+    static constexpr int ST1 = (N + QB) * 128;                 // 40 KB: K rows then Q rows of one 64-channel step
+    static constexpr int P_BYTES = QB * N * 2;                 // 32 KB
+    static constexpr int MAX_C = 512;
+    static constexpr int ST2 = MAX_C * 64;                     // 32 KB: C rows x 32 keys
+    static constexpr int RED_OFF = P_BYTES + 3 * ST2;          // 128 KB
+    static constexpr int LDS_BYTES = RED_OFF + 2 * 4 * QB * 4;
+    static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a) {
+    using C = AttnFusedCfg;
+    using T = __bf16;
+    constexpr int N = C::N, QB = C::QB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The four query blocks of an image run on the SAME XCD (block id % 8, used for speed only), back to back: the image's K and V^T are
+    // fetched into that XCD's L2 once and the other three workgroups hit it, instead of four XCDs each pulling them through the fabric.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int qb = seq & 3, b = (seq >> 2) * 8 + xcd;
+    if (b >= a.B) return;
+    const int Cc = a.C;
+
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto make_q = [](const void* p, unsigned bytes) __attribute__((always_inline)) {
+        const unsigned long long v = (unsigned long long)p;
+        return i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+    };
+    const i32x4 q_qk = make_q(a.qk, a.qk_bytes), q_vt = make_q(a.vT, a.vt_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma16 = [&](const i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff)
+                     : "memory");
+    };
+
+    // ---- phase-1 DMA geometry: 40 pieces of 8 rows x 128 B per step, five per wave; pieces 0-31 = key rows, 32-39 = query rows
+    unsigned v1[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int piece = wave * 5 + j;
+        const int row = piece * 8 + (lane >> 3);                       // row of the stage image (keys 0..255, then queries 0..63)
+        const int u = (lane & 7) ^ ((row >> 1) & 7);
+        const bool isk = row < N;
+        const int tok = isk ? row : qb * QB + (row - N);
+        v1[j] = (unsigned)((((long long)b * N + tok) * (2 * Cc) + (isk ? Cc : 0)) * 2 + u * 16);
+    }
+    auto issue1 = [&](int step, int buf) __attribute__((always_inline)) {
+        const unsigned base = lds0 + buf * C::ST1 + wave * (5 * 1024);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dma16(q_qk, base + j * 1024, v1[j], step * 128);
+    };
+    // ---- phase-2 DMA geometry: C / 16 pieces of 16 rows x 64 B per 32-key chunk (conv kernel's rotated 64-byte rows)
+    const int p2 = Cc / 16;                                            // pieces per chunk (<= 32)
+    const int un2 = (lane & 3) ^ ((lane >> 3) & 2);
+    unsigned v2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j;
+        const int row = piece * 16 + (lane >> 2);                      // channel
+        v2[j] = piece < p2 ? (unsigned)((((long long)b * Cc + row) * N) * 2 + un2 * 16) : 0xFFFF0000u;
+    }
+    auto issue2 = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned base = lds0 + C::P_BYTES + buf * C::ST2 + wave * (4 * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(q_vt, base + j * 1024, v2[j], chunk * 64);
+    };
+
+    // =========================== phase 1: S^T = K . Q^T ===========================
+    const int wm = wave >> 1, wn = wave & 1;                           // key block of 64, query block of 32
+    const int sw = (lane >> 1) & 7, ku = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int slot = (ks * 4 + ku) ^ sw;
+        a_off[ks] = (wm * 64 + (lane & 15)) * 128 + slot * 16;                   // key rows
+        b_off[ks] = N * 128 + (wn * 32 + (lane & 15)) * 128 + slot * 16;         // query rows
+    }
+    f32x4 s_acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = Cc / 64;
+    issue1(0, 0);
+    if (nk > 1) issue1(1, 1);
+    {
+        int buf = 0;
+        for (int k = 0; k < nk; ++k) {
+            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < nk) issue1(k + 2, buf >= 1 ? buf - 1 : 2);
+            const char* base = smem + buf * C::ST1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const uint4*)(base + a_off[ks] + i * (16 * 128));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *(const uint4*)(base + b_off[ks] + j * (16 * 128));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma16<T>(s_acc[i][j], af[i], bf[j]);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // every wave is done with the phase-1 stages
+    __builtin_amdgcn_sched_barrier(0);
+    issue2(0, 0);                                                      // the first V^T chunks travel while the softmax runs
+    issue2(1, 1);
+
+    // =========================== softmax over the keys, per query ===========================
+    // lane: query column wn*32 + j*16 + (lane & 15); keys wm*64 + i*16 + (lane >> 4)*4 + r
+    float* red = (float*)(smem + C::RED_OFF);                          // [2][4 key blocks][64 queries]
+    const float sl2 = a.alpha * 1.4426950408889634f;                   // scores in log2 units
+    float mx[2], sm[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s_acc[i][j][r] *= sl2; m = fmaxf(m, s_acc[i][j][r]); }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 16) red[wm * QB + wn * 32 + j * 16 + lane] = m;
+        mx[j] = m;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qn = wn * 32 + j * 16 + (lane & 15);
+        const float m = fmaxf(fmaxf(red[qn], red[QB + qn]), fmaxf(red[2 * QB + qn], red[3 * QB + qn]));
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s_acc[i][j][r] - m); s_acc[i][j][r] = e; s += e; }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 16) red[4 * QB + wm * QB + qn] = s;
+        sm[j] = s;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // P[query][key] bf16 into LDS: row = query (512 B), 16-byte unit u (8 keys) in slot u ^ (row & 15); this lane owns 4 consecutive keys
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qn = wn * 32 + j * 16 + (lane & 15);
+        const float* r4 = red + 4 * QB;
+        const float inv = 1.0f / (r4[qn] + r4[QB + qn] + r4[2 * QB + qn] + r4[3 * QB + qn]);       // fixed order: identical in every wave
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key0 = wm * 64 + i * 16 + (lane >> 4) * 4;
+            const int unit = key0 >> 3, half = (key0 >> 2) & 1;
+            const unsigned lo = TI<T>::pack2(s_acc[i][j][0] * inv, s_acc[i][j][1] * inv), hi = TI<T>::pack2(s_acc[i][j][2] * inv, s_acc[i][j][3] * inv);
+            *(uint2*)(smem + qn * 512 + ((unit ^ (qn & 15)) << 4) + half * 8) = make_uint2(lo, hi);
+        }
+    }
+    (void)mx; (void)sm;
+
+    // =========================== phase 2: O^T = V^T . P^T ===========================
+    // wave = block of C/8 channels; fragments: A = V^T rows (channels), B = P rows (queries); K = 32 keys per chunk
+    const int cw = Cc / 8;                                             // channels per wave: 8 ... 64
+    const int nfi = cw / 16;                                           // channel fragments per wave (C multiple of 128)
+    f32x4 o_acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int va_off = C::P_BYTES + lds_off(wave * cw + (lane & 15), ku);                 // + i * 16 rows * 64 B
+    int pb_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pb_off[j] = (j * 16 + (lane & 15)) * 512;                // + ((chunk*4 + ku) ^ (row & 15)) << 4
+    const int prow15 = lane & 15;
+    {
+        int buf = 0;
+        for (int k = 0; k < N / 32; ++k) {
+            if (k + 1 < N / 32) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // (k = 0: also makes every wave's P visible)
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < N / 32) issue2(k + 2, buf >= 1 ? buf - 1 : 2);
+            const char* vb = smem + buf * C::ST2;
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nfi) af[i] = *(const uint4*)(vb + va_off + i * (16 * 64));
+            const int pslot = ((k * 4 + ku) ^ prow15) << 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const uint4*)(smem + pb_off[j] + pslot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nfi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<T>(o_acc[i][j], af[i], bf[j]);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+    // ---- epilogue: lane holds 4 consecutive channels (rows of the fragment) of query j*16 + (lane & 15)
+    T* op = (T*)a.o + ((long long)b * N + qb * QB) * Cc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nfi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qn = j * 16 + (lane & 15);
+                const int c0 = wave * cw + i * 16 + (lane >> 4) * 4;
+                *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0], o_acc[i][j][1]), TI<T>::pack2(o_acc[i][j][2], o_acc[i][j][3]));
+            }
+}
+
+}  // namespace wdm

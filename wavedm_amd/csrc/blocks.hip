@@ -268,11 +268,17 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     { Tens dummy; WDM_TRY(run_conv(c, w.v, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &dummy, Y_NCHW, vT)); }
     free_tens(c, hn);
 
+    Tens o;
+    if (attn_fused_eligible(c.dtype, N, C)) {
+        // scores, softmax and P.V in one kernel: S and P never leave the CU (attn_fused_kernel.h)
+        WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
+        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s));
+        c.ar->free(vT);
+    } else {
     float* S = nullptr;
     WDM_TRY(alloc_f32(c, (size_t)c.B * N * N, &S));
     void* P = c.ar->alloc((size_t)c.B * N * N * es);
     if (!P) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention P)");
-    Tens o;
     WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
     if (!c.dry) {
         ConvArgs a{};
@@ -298,6 +304,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
         WDM_TRY(launch_conv(p, MODE_P1, c.dtype, c.s));
     }
     c.ar->free(S); c.ar->free(P); c.ar->free(vT);
+    }
     free_tens(c, qk);
     WDM_TRY(run_conv(c, w.proj, MODE_P1, o, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true));
     free_tens(c, o);

@@ -154,6 +154,10 @@ inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int
     return (t16 || t8) && cin % 32 == 0 && sC0 % 64 == 0 && (sC0 + sC1) % 64 == 0;
 }
 
+// ---- fused attention core (attn.hip / attn_fused_kernel.h): qk [B][256][2C], vT [B][C][256] -> o [B][256][C], bf16
+bool attn_fused_eligible(int dtype, int N, int C);
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s);
+
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 
