@@ -70,6 +70,14 @@ def main(out_path):
     both = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(both, mine)
     ok = (not torch.equal(owns[0], owns[1])) and all(torch.equal(b, both[0]) for b in both) and torch.equal(t4.ema, t4.params)
+    # ... and one real iteration of the loop body (DenoisingDiffusion_Wavelet.train_step: DWT, q-sample, loss, backward, gradient all-reduce,
+    # Adam, EMA) on DIFFERENT crops and noise per rank must leave the ranks with identical parameters again
+    torch.manual_seed(2000 + rank)
+    crops = torch.rand(2, 6, 64, 64, generator=torch.Generator().manual_seed(50 + rank))
+    d4.train_step(crops)
+    after = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(after, t4.params.clone())
+    ok = ok and all(torch.equal(b, after[0]) for b in after) and not torch.equal(after[0], both[0]) and t4.step == 1
     flag = torch.tensor([1.0 if ok else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
