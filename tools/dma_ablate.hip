@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
     a.w = w; a.w_tap_stride = (long long)Cout * Cin; a.w_row_stride = Cin; a.w_rows = Cout; a.bias = bias; a.alpha = 1.f;
     a.pro = pro; a.scale = sc; a.shift = sh; a.y = y; a.y_mode = Y_NHWC; a.y_s = Cout;
     a.x0_bytes = (unsigned)(nx * 2); a.w_bytes = (unsigned)(nw * 2);
+    if (getenv("SM")) { a.w_tap_stride = (long long)Cout * 32; a.w_row_stride = 32; a.w_slab_stride = 9 * Cout * 32; }      // slab-major weights
     using C = ConvDmaCfg;
     auto kern = conv_dma_kernel<4, 2, 4, 4>;
     a.mtiles = B * (H / 16) * (H / 16); a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;

@@ -24,6 +24,12 @@ int pack_conv_w(Scratch& sc, const float* w, const float* b, int cin, int cout, 
     out->cin = cin; out->cout = cout; out->k = k; out->rows_pad = conv_rows_pad(cout);
     WDM_TRY(k_pack_conv(w, cout, cin, k, dst, out->rows_pad, 0, 1, dtype, s));
     out->w = dst; out->b = b;
+    if (conv_sm_eligible(dtype, k, cin)) {              // same selection as the UNet executor: the slab-major copy next to the plain matrix
+        char* sm;
+        WDM_TRY(sc.get<char>(conv_packed_bytes(cin, cout, k, dtype), &sm));
+        WDM_TRY(k_pack_conv_sm(w, cout, cin, sm, out->rows_pad, s));
+        out->w_sm = sm;
+    }
     return WDM_OK;
 }
 

@@ -12,13 +12,13 @@ bool attn_fused_eligible(int dtype, int N, int C) {
     return on && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C;
 }
 
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s) {
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias) {
     using Cf = AttnFusedCfg;
     if (!qk || !vT || !o || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
     const double qkb = (double)B * Cf::N * 2.0 * C * 2.0, vtb = (double)B * C * Cf::N * 2.0;
     if (qkb >= 4294901760.0) WDM_FAIL(WDM_EINVAL, "attn(fused): q|k tensor exceeds the 4 GB buffer-offset range");
     AttnFusedArgs a{};
-    a.qk = qk; a.vT = vT; a.o = o; a.B = B; a.C = C;
+    a.qk = qk; a.vT = vT; a.o = o; a.vbias = vbias; a.B = B; a.C = C;
     a.alpha = (float)std::pow((double)C, -0.5);
     a.qk_bytes = (unsigned)qkb; a.vt_bytes = (unsigned)vtb;
     static std::atomic<unsigned> devs{0};

@@ -27,6 +27,7 @@ struct AttnFusedArgs {
     const void* qk;      // [B][256][2C] bf16
     const void* vT;      // [B][C][256] bf16
     void* o;             // [B][256][C] bf16
+    const float* vbias;  // [C] or nullptr: added to the output rows (the rows of P sum to 1, so P.(V + 1 b^T) = P.V + 1 b^T: V^T is stored without it)
     int B, C;
     float alpha;         // C^-1/2
     unsigned qk_bytes, vt_bytes;
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
             for (int j = 0; j < 4; ++j) {
                 const int qn = j * 16 + (lane & 15);
                 const int c0 = wave * cw + i * 16 + (lane >> 4) * 4;
-                *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0], o_acc[i][j][1]), TI<T>::pack2(o_acc[i][j][2], o_acc[i][j][3]));
+                const float4 vb = a.vbias ? *(const float4*)(a.vbias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0] + vb.x, o_acc[i][j][1] + vb.y), TI<T>::pack2(o_acc[i][j][2] + vb.z, o_acc[i][j][3] + vb.w));
             }
 }
 

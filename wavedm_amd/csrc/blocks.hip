@@ -111,6 +111,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.Cin = Cin; a.Cout = w.cout;
     a.w = w.w; a.w_tap_stride = (long long)w.rows_pad * w.cin; a.w_img_stride = 0; a.w_row_stride = w.cin; a.w_rows = w.rows_pad;
     a.w_bytes = (unsigned)((size_t)w.k * w.k * w.rows_pad * w.cin * dsize(c.dtype));
+    a.w_sm = (mode == MODE_S1 && w.k == 3) ? w.w_sm : nullptr;
     a.bias = w.b; a.alpha = 1.0f;
     a.pro = scale ? 1 : 0; a.scale = scale; a.shift = shift;
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
@@ -265,14 +266,36 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));   // [B][N][2C]
     void* vT = c.ar->alloc((size_t)c.B * C * N * es);                                                               // [B][C][N]
     if (!vT) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention V^T)");
-    { Tens dummy; WDM_TRY(run_conv(c, w.v, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &dummy, Y_NCHW, vT)); }
+    const bool fused = attn_fused_eligible(c.dtype, N, C);
+    // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
+    // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
+    // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
+    static int vt_gemm = -1;
+    if (vt_gemm < 0) { const char* e = getenv("WDM_ATTN_VT"); vt_gemm = (e && e[0] == '0') ? 0 : 1; }
+    const bool v_as_gemm = fused && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
+    if (v_as_gemm) {
+        if (!c.dry) {
+            ConvArgs a{};
+            a.x0 = w.v.w; a.C0 = C; a.xs0 = C; a.C1 = 0; a.x_img_shared = 1;
+            a.B = c.B; a.Hin = a.Hout = C / 16; a.Win = a.Wout = 16;
+            a.Cin = C; a.Cout = N;
+            a.w = hn.p; a.w_tap_stride = 0; a.w_img_stride = (long long)N * hn.xs; a.w_row_stride = hn.xs; a.w_rows = N;
+            a.w_bytes = (unsigned)((size_t)N * hn.xs * es);
+            a.alpha = 1.0f;
+            a.y = vT; a.y_mode = Y_NHWC; a.y_s = N;
+            WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
+        }
+    } else {
+        Tens dummy;
+        WDM_TRY(run_conv(c, w.v, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &dummy, Y_NCHW, vT));
+    }
     free_tens(c, hn);
 
     Tens o;
-    if (attn_fused_eligible(c.dtype, N, C)) {
+    if (fused) {
         // scores, softmax and P.V in one kernel: S and P never leave the CU (attn_fused_kernel.h)
         WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
-        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s));
+        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr));
         c.ar->free(vT);
     } else {
     float* S = nullptr;

@@ -76,6 +76,7 @@ struct Ctx {
 struct ConvW {
     const void* w = nullptr;   // [taps][rows_pad][cin] model dtype
     const void* w_up4 = nullptr;   // Upsample convs, bf16: the 16 pre-summed sub-pixel taps (k_pack_up4), or nullptr
+    const void* w_sm = nullptr;    // bf16 3x3 convs: slab-major copy [cin / 32][tap][rows_pad][32] (k_pack_conv_sm), or nullptr
     const float* b = nullptr;  // [cout]
     int cin = 0, cout = 0, k = 1, rows_pad = 0;
 };
@@ -137,6 +138,11 @@ int k_linear(const float* in, int n, int k, const float* W, const float* b, int 
 // cin_dst > cin: destination rows are cin_dst long, the extra columns zero (0 = cin)
 int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int rows_total, int row_off, int zero_tail,
                 int dtype, hipStream_t s, int cin_dst = 0);
+// slab-major copy for the LDS-DMA kernels: OIHW f32 3x3 -> [cin / 32][tap][rows_total][32] bf16 (rows >= cout zero): a weight sub-stage's rows are
+// 64 B each, and in the plain matrix a 1 KB DMA piece touches 16 half cache lines (27.6 cycles of the CU's vector-memory path, tools/dma_ubench.hip);
+// here it is one contiguous run of 8 whole lines (15 cycles)
+inline bool conv_sm_eligible(int dtype, int k, int cin) { return dtype == WDM_BF16 && k == 3 && cin % 32 == 0; }
+int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s);
 int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s);
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout);      // sub-pixel Upsample kernel applies to this low-resolution map
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
@@ -156,7 +162,8 @@ inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int
 
 // ---- fused attention core (attn.hip / attn_fused_kernel.h): qk [B][256][2C], vT [B][C][256] -> o [B][256][C], bf16
 bool attn_fused_eligible(int dtype, int N, int C);
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s);
+// vbias != nullptr: vT was computed without the v bias, which is added to the output instead
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr);
 
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);

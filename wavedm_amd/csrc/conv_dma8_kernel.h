@@ -12,25 +12,38 @@
 #pragma once
 #include "conv_kernel.h"
 
+#ifndef WDM_D8ABL
+#define WDM_D8ABL 0         // tools/dma8_ablate.hip: 2 = no MFMAs, 16 (with 2) = no fragment reads either, 4 = no halo DMA, 8 = no weight DMA
+#endif
+
 namespace wdm {
 
+// BN_ = 64: waves 2 (M) x 2 (N), 64 x 32 wave tiles.  BN_ = 48: waves 4 (M) x 1 (N), 32 x 48 wave tiles -- for Cout = 768 at batch 64 the 64-wide
+// tile gives 384 workgroups on 512 slots (half the CUs run two, half one: scripts/dma8_fill_probe.py, 55.8 us where a full 512 takes 62), the
+// 48-wide one exactly 512 of 3/4 the size.  The weight sub-stage keeps its 12 KB image (rows >= 3 * 48 are never fetched).
+template <int BN_>
 struct ConvDma8Cfg {
-    static constexpr int TH = 8, TW = 8, NI = 2, WAVES_M = 2, WAVES_N = 2, WM = 4, WN = 2;
-    static constexpr int NWAVES = 4, NTHREADS = 256, BN = 64, BK = 32;
+    static_assert(BN_ == 64 || BN_ == 48, "N tile");
+    static constexpr int TH = 8, TW = 8, NI = 2;
+    static constexpr int WAVES_M = BN_ == 64 ? 2 : 4, WAVES_N = BN_ == 64 ? 2 : 1, WM = BN_ == 64 ? 4 : 2, WN = BN_ == 64 ? 2 : 3;
+    static constexpr int NJ = BN_ == 64 ? 0 : 1;                // epilogue: 16-column fragments per pass (0 = default pair)
+    static constexpr int NWAVES = 4, NTHREADS = 256, BN = BN_, BK = 32;
     static constexpr int PH = 10, PW = 10, RS = 16;
     static constexpr int PLANE_IMG = PH * RS;                   // 160 row slots per image
     static constexpr int A_ROWS = NI * PLANE_IMG;               // 320
     static constexpr int A_CPW = 5, B_CPW = 3;                  // 1 KB DMA pieces per wave: 20 halo pieces, 12 per weight sub-stage
     static constexpr int A_BYTES = 20 * 1024;
-    static constexpr int B_SUB = 3 * BN * 64;                   // 12 KB
+    static constexpr int B_SUB = 3 * 64 * 64;                   // 12 KB
     static constexpr int B_OFF = 2 * A_BYTES;
     static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 76 KB: two workgroups per CU
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
     static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 80 * 1024, "LDS");
+    static_assert(WAVES_M * WM * 16 == NI * TH * TW && WAVES_N * WN * 16 == BN, "tile");
 };
 
+template <int BN_>
 __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
-    using C = ConvDma8Cfg;
+    using C = ConvDma8Cfg<BN_>;
     using T = __bf16;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, NI = C::NI, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,21 +103,22 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
     for (int i = 0; i < BCP; ++i) {
         const int r = (wave * BCP + i) * 16 + (lane >> 2);  // row of the sub-stage tile: [dy][n]
         const int dy = r / BN, n = n0 + (r - dy * BN);
-        b_v[i] = n < a.w_rows ? (unsigned)(((long long)dy * 3 * a.w_tap_stride + (long long)n * a.w_row_stride) * 2 + un * 16) : OOB;
+        b_v[i] = (dy < 3 && n < a.w_rows) ? (unsigned)(((long long)dy * 3 * a.w_tap_stride + (long long)n * a.w_row_stride) * 2 + un * 16) : OOB;
     }
     const int nslab = a.Cin / C::BK;
+    const int wslab = a.w_slab_stride ? a.w_slab_stride : C::BK;
     auto issue_b = [&](int s, int j, int ring) __attribute__((always_inline)) {
         const int sc_ = s < nslab ? s : nslab - 1;          // clamped: uniform DMA counts, the extra pieces land in buffers nobody reads again
-        const int soff = (int)(((long long)j * a.w_tap_stride + sc_ * C::BK) * 2);
+        const int soff = (int)(((long long)j * a.w_tap_stride + (long long)sc_ * wslab) * 2);
         const unsigned base = lds0 + C::B_OFF + ring * C::B_SUB;
 #pragma unroll
-        for (int i = 0; i < BCP; ++i) dma16(q_w, base + (wave * BCP + i) * 1024, b_v[i], soff);
+        for (int i = 0; i < BCP; ++i) if (!(WDM_D8ABL & 8)) dma16(q_w, base + (wave * BCP + i) * 1024, b_v[i], soff);
     };
     auto issue_a = [&](int s) __attribute__((always_inline)) {
         const int sc_ = s < nslab ? s : nslab - 1;
         const unsigned base = lds0 + (s & 1) * C::A_BYTES;
 #pragma unroll
-        for (int i = 0; i < ACP; ++i) dma16(q_x0, base + (wave * ACP + i) * 1024, a_v0[i], sc_ * C::BK * 2);
+        for (int i = 0; i < ACP; ++i) if (!(WDM_D8ABL & 4)) dma16(q_x0, base + (wave * ACP + i) * 1024, a_v0[i], sc_ * C::BK * 2);
     };
 
     // fragment addresses: a 16-row MFMA group covers two image rows, so one address per (group, dx); dy is a row-stride offset (RS = 16
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
     // reads five "even" row pairs (rows 2j, 2j + 1: dy = 0 and 2) and four "odd" ones (rows 2j + 1, 2j + 2: dy = 1) -- nine fragment reads
     // instead of twelve (these layers are LDS-bound).  Wave row wave_m is image wave_m of the tile, so group i + 1 = WM is halo rows 8, 9.
     auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
+        if ((WDM_D8ABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
         const char* pb = smem + dx * C::B_SUB;
         uint4 ae[WM + 1], ao[WM];
@@ -148,7 +163,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], dy == 0 ? ae[i] : dy == 1 ? ao[i] : ae[i + 1], bfr[j]);
+                for (int j = 0; j < WN; ++j) {
+                    const uint4& af = dy == 0 ? ae[i] : dy == 1 ? ao[i] : ae[i + 1];
+                    if (WDM_D8ABL & 2) { acc[i][j][0] += __uint_as_float(af.x ^ bfr[j].x); } else mma16<T>(acc[i][j], af, bfr[j]);
+                }
         }
     };
 #define WDM_DMA8_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
     // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1), as in
     // conv_dma_kernel.h: a plain GEMM over the tile's 128 pixels, 64 channels per K step, three 24 KB stages over the idle operand buffers
     if (a.sx0 != nullptr) {
-        constexpr int G_A = 128 * 128, G_STAGE = G_A + BN * 128;
+        constexpr int G_A = 128 * 128, G_STAGE = G_A + 64 * 128;
         static_assert(3 * G_STAGE <= C::LDS_BYTES, "shortcut ring");
         const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
         unsigned g_a0[4], g_a1[4], g_b[2];
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
             const int row = (wave * 2 + i) * 8 + (lane >> 3);          // 0..63
             const int u = (lane & 7) ^ ((row >> 1) & 7);
             const int n = n0 + row;
-            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
+            g_b[i] = (row < BN && n < a.sw_rows) ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
         }
         auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
             const int c = k * 64;
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    conv_epilogue<T, TH, TW, WM, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0);
+    conv_epilogue<T, TH, TW, WM, WN, C::NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0);
 }
 
 }  // namespace wdm

@@ -131,12 +131,13 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         b_v[i] = n < a.w_rows ? (unsigned)(((long long)dy * 3 * a.w_tap_stride + (long long)n * a.w_row_stride) * 2 + un * 16) : OOB;
     }
     const int nslab = a.Cin / C::BK;
+    const int wslab = a.w_slab_stride ? a.w_slab_stride : C::BK;
     // weight sub-stage (slab s, column j) -> ring buffer `ring`; slabs past the end are clamped (the extra pieces land in buffers
     // nobody reads again and keep the per-sub-stage DMA counts, hence the vmcnt constants, uniform)
     auto issue_b = [&](int s, int j, int ring) __attribute__((always_inline)) {
         if ((WDM_DABL & 8) && s > 0) return;
         const int sc_ = s < nslab ? s : nslab - 1;
-        const int soff = (int)(((long long)j * a.w_tap_stride + sc_ * C::BK) * 2);
+        const int soff = (int)(((long long)j * a.w_tap_stride + (long long)sc_ * wslab) * 2);
         const unsigned base = lds0 + C::B_OFF + ring * C::B_SUB;
 #pragma unroll
         for (int i = 0; i < BCP; ++i) dma16(q_w, base + (wave * BCP + i) * 1024, b_v[i], soff);

@@ -61,6 +61,9 @@ struct ConvArgs {
     const void* w;         // [tap][row][cin] (row = output channel), model dtype
     long long w_tap_stride, w_img_stride;  // elements; w_img_stride != 0: per-image weights (attention)
     int w_row_stride;      // elements
+    const void* w_sm;      // slab-major copy of w, [slab][tap][row][32] (bf16 3x3 layers, k_pack_conv_sm), or nullptr: the 8x8 LDS-DMA kernel reads it
+    int w_slab_stride;     // LDS-DMA 3x3 kernels: elements between the 32-channel slabs of a weight row (0 = 32: the plain [tap][row][cin] matrix;
+                           // slab-major copies [slab][tap][row][32], ConvW::w_sm, make every 1 KB DMA piece one contiguous run of whole cache lines)
     int w_rows;            // informational: rows of the weight matrix (columns >= Cout are never stored)
     unsigned x0_bytes, x1_bytes, w_bytes;   // extents for the buffer descriptors (reads past them return 0)
     const float* bias;     // [Cout] or nullptr
@@ -97,6 +100,8 @@ struct ConvArgs {
     //   w + b * w_img_stride + (tap % 3) * w_tx_stride + (tap / 3 - 1) * w_ty_stride        (img_mod == 0: off)
     int img_mod;
     long long w_tx_stride, w_ty_stride;
+    int x_img_shared;      // 1: every image of the batch reads the rows of image 0 of x0 (the A operand is a weight matrix and the per-image
+                           // "weights" are activations: V^T = W_v . h^T of the attention block)
     // sub-pixel form of Upsample (conv_up4_kernel.h): the grid is the LOW-resolution map, N tile nt belongs to output phase nt / up4_ntp
     // (py = phase >> 1, px = phase & 1) and writes pixel (2 oy + py, 2 ox + px) of the (2 Hout) x (2 Wout) output
     int up4, up4_ntp;
@@ -109,7 +114,7 @@ __host__ __device__ inline long long conv_w_img_offset(const ConvArgs& a, int im
     const int tap = img / a.img_mod, b = img - tap * a.img_mod;
     return (long long)b * a.w_img_stride + (long long)(tap % 3) * a.w_tx_stride + (long long)(tap / 3 - 1) * a.w_ty_stride;
 }
-__host__ __device__ inline int conv_x_img(const ConvArgs& a, int img) { return a.img_mod ? img % a.img_mod : img; }
+__host__ __device__ inline int conv_x_img(const ConvArgs& a, int img) { return a.x_img_shared ? 0 : a.img_mod ? img % a.img_mod : img; }
 
 // ------------------------------------------------------------------------------------------------
 // small helpers

@@ -560,6 +560,25 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
+__global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restrict__ w, int cout, int cin, __bf16* __restrict__ dst, int rows_total) {
+    const long long total = (long long)9 * rows_total * cin;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 31);
+        const int o = (int)((id >> 5) % rows_total);
+        const int tap = (int)((id / ((long long)32 * rows_total)) % 9);
+        const int slab = (int)(id / ((long long)32 * rows_total * 9));
+        const float v = o < cout ? w[((long long)o * cin + slab * 32 + c) * 9 + tap] : 0.f;
+        dst[id] = (__bf16)v;
+    }
+}
+int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s) {
+    if (cin % 32) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 32", cin);
+    const long long total = (long long)9 * rows_total * cin;
+    const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
+    hipLaunchKernelGGL(pack_conv_sm_kernel, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst, rows_total);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
 // Upsample in sub-pixel form (conv_up4_kernel.h): OIHW f32 3x3 -> [phase = 2 py + px][dy'][dx'][rows_total][cin] bf16, the taps of the
 // upsampled grid that fall on the same low-resolution pixel summed in fp32:  py = 0: {w0}, {w1 + w2};  py = 1: {w0 + w1}, {w2}
 __global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__ w, int cout, int cin, __bf16* __restrict__ dst, int rows_total) {

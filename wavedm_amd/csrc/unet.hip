@@ -27,12 +27,13 @@ struct ParamSlot {
     int row_off = 0;      // PK_CONV: first destination row;  PK_F32: element offset inside the destination vector
     bool zero_tail = true;   // PK_CONV: this slot also zero-fills the padding rows behind it
     int cin_dst = 0;         // PK_CONV: row length of the destination when it is padded beyond shape[1] (conv_in), else 0
+    size_t sm_off = 0;       // PK_CONV of a bf16 3x3 conv: second destination, the slab-major copy (k_pack_conv_sm); 0 = none
     size_t up4_off = 0;      // PK_CONV of an Upsample conv (bf16): second destination, the 16 sub-pixel taps (k_pack_up4); 0 = none
     bool loaded = false;
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 };
 
-struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; size_t up4_off; };
+struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; size_t up4_off, sm_off; };
 struct NormD { size_t g_off, b_off; int c; };
 struct ResD { int cin, cout; NormD n1, n2; ConvD c1, c2, nin; bool has_nin; int temb_row; };
 struct AttnD { int c; NormD n; ConvD qk, v, proj; };
@@ -77,6 +78,10 @@ struct wdm_unet {
         d.b_off = take((size_t)cout * 4);
         add_param(name + ".weight", {cout, cin, k, k}, PK_CONV, d.w_off, d.rows_pad, 0);
         params.back().cin_dst = cin_pad != cin ? cin_pad : 0;
+        if (cin_pad == cin && conv_sm_eligible(cfg.dtype, k, cin)) {
+            d.sm_off = take(conv_packed_bytes(cin, cout, k, cfg.dtype));
+            params.back().sm_off = d.sm_off;
+        }
         add_param(name + ".bias", {cout}, PK_F32, d.b_off, 0, 0);
         return d;
     }
@@ -124,7 +129,7 @@ struct wdm_unet {
     }
 
     int build();
-    ConvW cw(const ConvD& d) const { ConvW w; w.w = packed + d.w_off; w.w_up4 = d.up4_off ? packed + d.up4_off : nullptr; w.b = (const float*)(packed + d.b_off); w.cin = d.cin; w.cout = d.cout; w.k = d.k; w.rows_pad = d.rows_pad; return w; }
+    ConvW cw(const ConvD& d) const { ConvW w; w.w = packed + d.w_off; w.w_up4 = d.up4_off ? packed + d.up4_off : nullptr; w.w_sm = d.sm_off ? packed + d.sm_off : nullptr; w.b = (const float*)(packed + d.b_off); w.cin = d.cin; w.cout = d.cout; w.k = d.k; w.rows_pad = d.rows_pad; return w; }
     NormW nw(const NormD& d) const { NormW n; n.g = (const float*)(packed + d.g_off); n.b = (const float*)(packed + d.b_off); n.c = d.c; return n; }
     ResW rw(const ResD& d, const float* temb_all, int n_t) const {
         ResW r;
@@ -372,6 +377,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
+        if (p.sm_off) WDM_TRY(k_pack_conv_sm(dev_src, cout, cin, u->packed + p.sm_off, p.rows_total, s));
         if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s));
     } else {
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
