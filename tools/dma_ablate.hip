@@ -30,6 +30,14 @@ int main(int argc, char** argv) {
     a.pro = pro; a.scale = sc; a.shift = sh; a.y = y; a.y_mode = Y_NHWC; a.y_s = Cout;
     a.x0_bytes = (unsigned)(nx * 2); a.w_bytes = (unsigned)(nw * 2);
     if (getenv("SM")) { a.w_tap_stride = (long long)Cout * 32; a.w_row_stride = 32; a.w_slab_stride = 9 * Cout * 32; }      // slab-major weights
+    if (getenv("FULL")) {       // what the model's layers also carry: GroupNorm partial statistics of the output, temb rows, a residual
+        const int nslab = (H / 16) * (H / 16) * 4;
+        float* st; float* temb; unsigned short* res;
+        CK(hipMalloc(&st, (size_t)B * nslab * Cout * 16)); CK(hipMalloc(&temb, (size_t)B * Cout * 4)); CK(hipMalloc(&res, ny * 2));
+        CK(hipMemset(temb, 0, (size_t)B * Cout * 4)); CK(hipMemset(res, 0, ny * 2));
+        a.stats = st; a.stats_nslab = nslab; a.temb = temb; a.temb_ld = Cout; a.temb_per_image = 1;
+        if (atoi(getenv("FULL")) > 1) { a.res = res; a.res_s = Cout; }
+    }
     using C = ConvDmaCfg;
     auto kern = conv_dma_kernel<4, 2, 4, 4>;
     a.mtiles = B * (H / 16) * (H / 16); a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;
@@ -38,12 +46,13 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
-    const int it = 20;
+    const int it = getenv("IT") ? atoi(getenv("IT")) : 20;
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, 0, a);      // settle the clocks
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * B * H * H * Cout * 9.0 * Cin;
-    printf("DABL=%2d B=%d H=%d %d->%d pro=%d grid=%d : %7.1f us  %7.1f TFLOP/s (nominal)\n", WDM_DABL, B, H, Cin, Cout, pro, grid, ms / it * 1e3, fl / (ms / it) / 1e9);
+    printf("DABL=%2d EABL=%d B=%d H=%d %d->%d pro=%d grid=%d : %7.1f us  %7.1f TFLOP/s (nominal)\n", WDM_DABL, WDM_EABL, B, H, Cin, Cout, pro, grid, ms / it * 1e3, fl / (ms / it) / 1e9);
     return 0;
 }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const uint4& af = dy == 0 ? ae[i] : dy == 1 ? ao[i] : ae[i + 1];
-                    if (WDM_D8ABL & 2) { acc[i][j][0] += __uint_as_float(af.x ^ bfr[j].x); } else mma16<T>(acc[i][j], af, bfr[j]);
+                    if (WDM_D8ABL & 2) { acc[i][j][0] += __uint_as_float(af.x ^ bfr[j].x); } else mma16t<T>(acc[i][j], af, bfr[j]);
                 }
         }
     };
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], af[i], bfr[j]);
             }
             buf = buf == 2 ? 0 : buf + 1;
         }

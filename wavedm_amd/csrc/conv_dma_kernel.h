@@ -215,7 +215,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     if (WDM_DABL & 2) { if (i == 0) acc[0][j][0] += __uint_as_float(bfr[j].x ^ ah[dy + (j & 3)].x); }   // one VALU per fragment keeps the reads alive
-                    else mma16<T>(acc[i][j], ah[i + dy], bfr[j]);
+                    else mma16t<T>(acc[i][j], ah[i + dy], bfr[j]);
                 }
         }
     };
@@ -330,7 +330,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], af[i], bfr[j]);
             }
             buf = buf == 2 ? 0 : buf + 1;
         }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     if (WDM_GABL & 2) acc[i][j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
-                    else mma16<T>(acc[i][j], af[i], bfr[j]);
+                    else mma16t<T>(acc[i][j], af[i], bfr[j]);
                 }
         }
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;

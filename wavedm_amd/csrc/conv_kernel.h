@@ -222,8 +222,19 @@ template <> __device__ __forceinline__ void mma16<f32x3_t>(f32x4& acc, const uin
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc, 0, 0, 0);
 }
 
+// The conv kernels multiply with the WEIGHT fragment as the MFMA's row operand and the pixel fragment as its column operand: the 16 x 16 result
+// fragment is then [channel][pixel], i.e. a lane holds 4 CONSECUTIVE CHANNELS (4 (lane >> 4) + 0..3) of ONE pixel (lane & 15) -- 8 / 16 contiguous
+// bytes of an NHWC row, stored straight from the accumulators (conv_epilogue_direct).  Both operands have the same register layout, so this costs
+// nothing in the main loop.
+template <typename T> __device__ __forceinline__ void mma16t(f32x4& acc, const uint4& pix, const uint4& wgt) { mma16<T>(acc, wgt, pix); }
+
+template <int N> __device__ __forceinline__ float dpp_row_ror(float x) {      // lane l of each row of 16 lanes gets the value of lane (l + N) mod 16
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+
 // ------------------------------------------------------------------------------------------------
-// epilogue: accumulators -> per-wave LDS tile (fp32) -> row-contiguous 16-byte global accesses.
+// epilogue, fallback form: accumulators -> per-wave LDS tile (fp32) -> row-contiguous 16-byte global accesses (channel-major and fp32-NCHW outputs,
+// channel counts that are not a multiple of 4).
 // The MFMA C layout gives a lane ONE channel of 4 pixels; storing from it directly costs one 2-byte store per
 // output (64 store instructions per lane, issue-bound).  Through LDS every lane owns 8 consecutive channels of
 // one pixel: alpha*acc + bias + temb + residual in fp32, then one 16-byte store (and one 16-byte residual load).
@@ -244,6 +255,7 @@ template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass>
 __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
                                                 int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
     constexpr int VEC = TI<T>::VEC;
+    constexpr int ES = 16 / VEC;                           // bytes per element of T
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);   // 16-column fragments per pass (NJ_ = WN: one pass, whole 128-byte rows per wave)
     constexpr int ECOLS = 16 * NJ;
     constexpr int ESTR = ECOLS + 4;                   // row stride (floats): 4*ESTR = 16 (mod 32) -> conflict-free writes
@@ -252,6 +264,10 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
     constexpr int RPI = 64 / LPR;                     // rows per iteration
     float* ep = (float*)smem + wave * (EROWS * ESTR);
     const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
+    // output / residual through raw buffer descriptors (extents checked on the host: conv_dispatch.inc)
+    const long long out_rows = a.up4 ? (long long)a.B * 4 * a.Hout * a.Wout : (a.m_valid ? (long long)a.m_valid : (long long)a.B * a.Hout * a.Wout);
+    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(unsigned)(out_rows * a.y_s * (a.y_mode == Y_NHWC ? ES : 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, a.res ? (int)(unsigned)(out_rows * a.res_s * ES) : 0, 0x00020000);
     // additive per-channel terms of BOTH passes, fetched up front as 16-byte loads so that their latency overlaps the LDS
     // transposes instead of opening every pass: bias + shortcut bias + temb.  A wave tile lies inside one image
     // (static_assert), so temb's row is a per-wave constant.
@@ -295,64 +311,98 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
         if (!active) continue;
         const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
         if (vec_ok) {
-            const int c8 = (lane % LPR) * 8;
+            // Addresses: pixel index = (wave-uniform part of iteration `it`) + (lane part, the same in every iteration) -- RPI and TW are powers of two,
+            // so the lane's row offset never carries into the uniform part.  The uniform part goes into the buffer instructions' scalar offset: no
+            // per-iteration vector integer math (the 64-bit index arithmetic of a plain pointer store was most of this loop's issue slots).
+            const int c8 = (lane % LPR) * 8, lp = lane / LPR;
             const int n = ncol0 + c8;
+            const bool ncol = n < a.Cout;
+            constexpr unsigned OOBV = 0xFFFF0000u;                 // beyond every extent (extents stay below it: conv_dispatch.inc)
+            const int es_y = a.y_mode == Y_NHWC ? ES : 4;
+            const int lane_pix = !a.up4 ? (lp / TW) * a.Wout + (lp % TW) : ((lp / TW) * 2) * (2 * a.Wout) + (lp % TW) * 2;
+            const unsigned vo_y = ncol ? (unsigned)((lane_pix * a.y_s + n) * es_y) : OOBV;
+            const unsigned vo_r = ncol ? (unsigned)((lane_pix * a.res_s + n) * ES) : OOBV;
             float bias8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bias8[e] = add8[jp / NJ][e];
             // GroupNorm partial statistics of the values as stored (optional): the final values go back into the LDS tile
             // and a column pass (lane = channel) sums them -- no cross-lane shuffles
             const bool do_stats = a.stats != nullptr;
+            constexpr int NIT = (EROWS + RPI - 1) / RPI;
+            constexpr bool RAGGED = EROWS % RPI != 0;              // fewer rows than one iteration covers (16-row wave tiles): the lanes past them idle
+            int so_pix[NIT];
+            bool img_ok[NIT];
+            int img_it[NIT];
 #pragma unroll
-            for (int it = 0; it < EROWS / RPI; ++it) {
-                const int rloc = it * RPI + lane / LPR;
-                const int m = wave_m * EROWS + rloc;
-                const int img = m / (TH * TW), rr = m % (TH * TW);
-                const int oy = oy0 + rr / TW, ox = ox0 + rr % TW;
-                const int img_g = img0 + img;
-                const bool valid = n < a.Cout && img_g < a.B &&
-                                   (a.m_valid == 0 || ((long long)img_g * a.Hout + oy) * a.Wout + ox < a.m_valid);
-                if (!valid && !do_stats) continue;
-                const float4 v0 = *(const float4*)(ep + rloc * ESTR + c8), v1 = *(const float4*)(ep + rloc * ESTR + c8 + 4);
+            for (int it = 0; it < NIT; ++it) {                    // wave-uniform (scalar) part
+                const int mu = wave_m * EROWS + it * RPI;
+                const int img_u = mu / (TH * TW), rru = mu % (TH * TW);
+                const int oyu = oy0 + rru / TW, oxu = ox0 + rru % TW;
+                const int img_g = img0 + img_u;
+                img_it[it] = img_g;
+                img_ok[it] = img_g < a.B;
+                so_pix[it] = !a.up4 ? (img_g * a.Hout + oyu) * a.Wout + oxu
+                                    : (img_g * (2 * a.Hout) + 2 * oyu + (phase >> 1)) * (2 * a.Wout) + 2 * oxu + (phase & 1);
+            }
+            // residual rows of the whole pass requested up front (bf16: one 16-byte load per iteration)
+            uint4 resv[VEC == 8 ? NIT : 1];
+            if (VEC == 8 && a.res != nullptr) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    unsigned vo = vo_r;
+                    if (a.m_valid != 0 && so_pix[it] + lane_pix >= a.m_valid) vo = OOBV;
+                    if (RAGGED && it * RPI + lp >= EROWS) vo = OOBV;
+                    resv[it] = img_ok[it] ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vo, so_pix[it] * a.res_s * ES, 0)) : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!img_ok[it]) continue;                         // wave-uniform: images past the batch (their statistics slabs are never written)
+                const int rloc = it * RPI + lp;
+                unsigned voy = vo_y, vor = vo_r;
+                if (a.m_valid != 0 && so_pix[it] + lane_pix >= a.m_valid) { voy = OOBV; vor = OOBV; }
+                const bool row_ok = !RAGGED || rloc < EROWS;
+                if (!row_ok) { voy = OOBV; vor = OOBV; }
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v0 = row_ok ? *(const float4*)(ep + rloc * ESTR + c8) : zero4, v1 = row_ok ? *(const float4*)(ep + rloc * ESTR + c8 + 4) : zero4;
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
-                const long long opix = !a.up4 ? ((long long)(valid ? img_g : 0) * a.Hout + oy) * a.Wout + ox
-                                              : ((long long)(valid ? img_g : 0) * (2 * a.Hout) + 2 * oy + (phase >> 1)) * (2 * a.Wout) + 2 * ox + (phase & 1);
-                if (valid) {
-                    if (!TEMB_IN_ADD && a.temb != nullptr) {
-                        const float* tp = a.temb + (long long)(a.temb_per_image ? img_g : 0) * a.temb_ld + n;
-                        const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
-                        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                if (!TEMB_IN_ADD && a.temb != nullptr && ncol) {
+                    const float* tp = a.temb + (long long)(a.temb_per_image ? img_it[it] : 0) * a.temb_ld + n;
+                    const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
+                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                }
+                if (a.res != nullptr) {
+                    float rf[8];
+                    if (VEC == 8) TI<T>::unpack(resv[it], rf);
+                    else {
+                        const int so = so_pix[it] * a.res_s * ES;
+                        TI<T>::unpack(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vor, so, 0)), rf);
+                        TI<T>::unpack(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vor + 16, so, 0)), rf + 4);
                     }
-                    if (a.res != nullptr) {
-                        float rf[8];
-                        const T* rp = (const T*)a.res + opix * a.res_s + n;
-                        if (VEC == 8) { TI<T>::unpack(*(const uint4*)rp, rf); }
-                        else { TI<T>::unpack(*(const uint4*)rp, rf); TI<T>::unpack(*(const uint4*)(rp + 4), rf + 4); }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] += rf[e];
                 }
                 float vr[8];                                   // the values as the consumer will read them back
-                if (a.y_mode == Y_NHWC) {
-                    T* yp = (T*)a.y + opix * a.y_s + n;
-                    if (VEC == 8) { const uint4 pk = TI<T>::pack(v); TI<T>::unpack(pk, vr); if (valid && !(WDM_EABL & 1)) *(uint4*)yp = pk; }
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vr[e] = v[e];
-                        if (valid) { *(uint4*)yp = TI<T>::pack(v); *(uint4*)(yp + 4) = TI<T>::pack(v + 4); }
-                    }
+                // The uniform part is added to the lane's offset instead of riding in the store's scalar-offset field: a 16-byte buffer store with an
+                // SGPR soffset was seen (gfx950, fp32 tiles) to pick up a data register that the NEXT VALU instruction overwrote -- the compiler
+                // inserts the wait state for that hazard only when soffset is not a register.  (The loads above have no data operand to race on.)
+                const unsigned vst = voy == OOBV ? OOBV : voy + (unsigned)(so_pix[it] * a.y_s * es_y);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                if (a.y_mode == Y_NHWC && VEC == 8) {
+                    const uint4 pk = TI<T>::pack(v);
+                    TI<T>::unpack(pk, vr);
+                    if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), r_y, (int)vst, 0, 0);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) vr[e] = v[e];
-                    if (valid) {
-                        float* yp = (float*)a.y + opix * a.y_s + n;
-                        *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-                        *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (!(WDM_EABL & 1)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r_y, (int)vst, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7])), r_y, (int)vst + 16, 0, 0);
                     }
                 }
-                if (do_stats) {
+                if (do_stats && row_ok) {
                     *(float4*)(ep + rloc * ESTR + c8) = make_float4(vr[0], vr[1], vr[2], vr[3]);
                     *(float4*)(ep + rloc * ESTR + c8 + 4) = make_float4(vr[4], vr[5], vr[6], vr[7]);
                 }
@@ -433,14 +483,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
     constexpr int ESTR = 16 * NJ + 4;
-    auto write_pass = [&](float* ep, int jp) __attribute__((always_inline)) {
+    auto write_pass = [&](float* ep, int jp) __attribute__((always_inline)) {      // [channel][pixel] fragments -> ep[pixel][channel]
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ep[(i * 16 + (lane >> 4) * 4 + r) * ESTR + jj * 16 + (lane & 15)] = acc[i][jp + jj][r];
+                *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
     conv_epilogue_w<T, TH, TW, WM, WN, NJ_>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
 }
@@ -728,7 +776,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 #pragma unroll
                         for (int j = 0; j < WN; ++j) {
                             if (WDM_ABL & 8) { acc[i][j][0] += __uint_as_float(ah[i + dy].x ^ bfr[j].y); }
-                            else mma16<T>(acc[i][j], ah[i + dy], bfr[j]);
+                            else mma16t<T>(acc[i][j], ah[i + dy], bfr[j]);
                         }
                 }
             }
@@ -762,7 +810,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     if (WDM_ABL & 8) { acc[i][j][0] += __uint_as_float(af[i].x ^ bfr[j].y); }   // keep the LDS reads alive
-                    else mma16<T>(acc[i][j], af[i], bfr[j]);
+                    else mma16t<T>(acc[i][j], af[i], bfr[j]);
                 }
         }
     };

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], ah[i + dyl], bfr[j]);
+                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], ah[i + dyl], bfr[j]);
             }
         } else {
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16<T>(acc[i][j], af[i], bfr[j]);
+                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], af[i], bfr[j]);
             }
         }
     };
