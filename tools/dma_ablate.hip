@@ -38,9 +38,19 @@ int main(int argc, char** argv) {
         a.stats = st; a.stats_nslab = nslab; a.temb = temb; a.temb_ld = Cout; a.temb_per_image = 1;
         if (atoi(getenv("FULL")) > 1) { a.res = res; a.res_s = Cout; }
     }
+#ifdef WDM_EPI_TS
+    unsigned long long* ts; CK(hipMalloc(&ts, 128 * 8)); CK(hipMemset(ts, 0, 128 * 8)); a.ts = ts;
+#endif
+#ifdef TILE32
+    using C = ConvDmaCfgT<4, 2, 8, 4, 32, 3>;
+    auto kern = conv_dma_kernel<4, 2, 8, 4, 32, 3>;
+    a.mtiles = B * (H / 32) * (H / 16);
+#else
     using C = ConvDmaCfg;
     auto kern = conv_dma_kernel<4, 2, 4, 4>;
-    a.mtiles = B * (H / 16) * (H / 16); a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;
+    a.mtiles = B * (H / 16) * (H / 16);
+#endif
+    a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;
     const int grid = 8 * a.ntiles * ((a.mtiles + 7) / 8);
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -54,5 +64,12 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * B * H * H * Cout * 9.0 * Cin;
     printf("DABL=%2d EABL=%d B=%d H=%d %d->%d pro=%d grid=%d : %7.1f us  %7.1f TFLOP/s (nominal)\n", WDM_DABL, WDM_EABL, B, H, Cin, Cout, pro, grid, ms / it * 1e3, fl / (ms / it) / 1e9);
+#ifdef WDM_EPI_TS
+    {
+        unsigned long long h[128]; CK(hipMemcpy(h, a.ts, sizeof(h), hipMemcpyDeviceToHost));
+        printf("stamps of workgroup %d (s_memtime ticks since kernel entry of wave 0): entry | main loop end | after barrier | tile written | rows stored | epilogue done | stores acknowledged | first stage ready | slab 1, 2, 3 start | setup done | first DMAs issued | table + DMAs landed\n", WDM_EPI_TS);
+        for (int w = 0; w < 8; ++w) { printf("  wave %d:", w); for (int k = 0; k < 14; ++k) printf(" %8lld", (long long)(h[w * 16 + k] - h[0])); printf("\n"); }
+    }
+#endif
     return 0;
 }

@@ -105,7 +105,15 @@ struct ConvArgs {
     // sub-pixel form of Upsample (conv_up4_kernel.h): the grid is the LOW-resolution map, N tile nt belongs to output phase nt / up4_ntp
     // (py = phase >> 1, px = phase & 1) and writes pixel (2 oy + py, 2 ox + px) of the (2 Hout) x (2 Wout) output
     int up4, up4_ntp;
+#ifdef WDM_EPI_TS
+    unsigned long long* ts;    // ablation builds (tools/dma_ablate.hip): s_memtime stamps of workgroup WDM_EPI_TS, [wave][8]
+#endif
 };
+#ifdef WDM_EPI_TS
+#define WDM_ETS(k) do { if (blockIdx.x == WDM_EPI_TS && (threadIdx.x & 63) == 0) a.ts[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WDM_ETS(k) do { } while (0)
+#endif
 
 // element offset of the weight matrix image `img` reads, and the image whose input it reads
 __host__ __device__ inline long long conv_w_img_offset(const ConvArgs& a, int img) {
@@ -303,11 +311,12 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
     for (int jp = 0; jp < WN; jp += NJ) {
         // The fp32 tile is private to the wave, and the LDS executes one wave's instructions in order: only the hand-over from the
         // main loop (other waves may still read the operand images this tile overlays) needs the workgroup barrier.
-        if (jp == 0) __syncthreads();
+        if (jp == 0) { WDM_ETS(1); __syncthreads(); WDM_ETS(2); }
         else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         if (active) write_pass(ep, jp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (jp == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WDM_ETS(3); }
         if (!active) continue;
         const int ncol0 = n0 + (wave_n * WN + jp) * 16;          // first channel of this pass
         if (vec_ok) {
@@ -355,6 +364,16 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                     resv[it] = img_ok[it] ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vo, so_pix[it] * a.res_s * ES, 0)) : make_uint4(0u, 0u, 0u, 0u);
                 }
             }
+            // the lane's rows of the tile, all requested before the first is used (one LDS round trip for the pass instead of one per iteration)
+            float4 tl[NIT][2];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rloc = it * RPI + lp;
+                const bool row_ok = !RAGGED || rloc < EROWS;
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                tl[it][0] = row_ok ? *(const float4*)(ep + rloc * ESTR + c8) : zero4;
+                tl[it][1] = row_ok ? *(const float4*)(ep + rloc * ESTR + c8 + 4) : zero4;
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (!img_ok[it]) continue;                         // wave-uniform: images past the batch (their statistics slabs are never written)
@@ -363,8 +382,7 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                 if (a.m_valid != 0 && so_pix[it] + lane_pix >= a.m_valid) { voy = OOBV; vor = OOBV; }
                 const bool row_ok = !RAGGED || rloc < EROWS;
                 if (!row_ok) { voy = OOBV; vor = OOBV; }
-                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v0 = row_ok ? *(const float4*)(ep + rloc * ESTR + c8) : zero4, v1 = row_ok ? *(const float4*)(ep + rloc * ESTR + c8 + 4) : zero4;
+                const float4 v0 = tl[it][0], v1 = tl[it][1];
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
@@ -407,6 +425,7 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                     *(float4*)(ep + rloc * ESTR + c8 + 4) = make_float4(vr[4], vr[5], vr[6], vr[7]);
                 }
             }
+            WDM_ETS(4);
             if (do_stats) {
                 // wave-local: the LDS executes one wave's instructions in order, so the column reads below see the
                 // write-backs above; the fence only stops the compiler from reordering them
@@ -491,6 +510,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
                 *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
     conv_epilogue_w<T, TH, TW, WM, WN, NJ_>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
+    WDM_ETS(5);
+#ifdef WDM_EPI_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WDM_ETS(6);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
