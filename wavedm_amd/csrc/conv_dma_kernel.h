@@ -186,7 +186,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         const int c = (s < nslab ? s : nslab - 1) * C::BK + un * 8;
         float sc[8], sh[8];
         *(float4*)&sc[0] = *(const float4*)(sct + c); *(float4*)&sc[4] = *(const float4*)(sct + c + 4);
-        *(float4*)&sh[0] = *(const float4*)(sct + a.Cin + c); *(float4*)&sh[4] = *(const float4*)(sct + a.Cin + c + 4);
+        *(float4*)&sh[0] = *(const float4*)(sct + C::MAX_CIN + c); *(float4*)&sh[4] = *(const float4*)(sct + C::MAX_CIN + c + 4);
         char* base = smem + (s & 1) * C::A_BYTES + lane * 16;
 #pragma unroll
         for (int i = 0; i < ACP; ++i) {
@@ -263,22 +263,31 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     // them: with three sub-stages of lead the (HBM-resident, 64-byte-gathered) halo pieces are no longer the ones the weight waits block on.
     const bool pro = a.pro != 0;
     WDM_ETS(11);
+    // The DMA queue retires in order, so what is needed first is requested first: the scale/shift rows of the image (plain loads), the halo slab, then
+    // the weights -- and each step waits only for its own operands: the table goes to LDS while the halo is in flight, the halo is transformed while
+    // the weights are, and the K loop starts on weights (0, 0) with (0, 1), (0, 2) still under way (its counted waits allow exactly that).
+    constexpr int NB0 = C::NRING == 4 ? 3 : 2;                               // weight sub-stages requested by the prologue
+    if (pro && wave * 256 < C::MAX_CIN) {
+        // scale / shift rows of the image by DMA as well (256 floats per piece, wave w takes floats [256 w, 256 w + 256) of each; past Cin the
+        // descriptor returns zeros): no compiler-visible load in the prologue, whose wait would drain the whole queue.  shift sits MAX_CIN floats
+        // behind scale whatever Cin is, so the zero fill of a short row never lands on it.
+        const i32x4 q_sc = make_q(a.scale + (long long)img0 * a.Cin, (unsigned)(a.Cin * 4)), q_sh = make_q(a.shift + (long long)img0 * a.Cin, (unsigned)(a.Cin * 4));
+        const unsigned vo = (unsigned)((wave * 256 + lane * 4) * 4);
+        dma16(q_sc, lds0 + C::SC_OFF + wave * 1024, vo, 0);
+        dma16(q_sh, lds0 + C::SC_OFF + C::MAX_CIN * 4 + wave * 1024, vo, 0);
+    }
     issue_a(0);
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
     if (C::NRING == 4) issue_b(0, 2, 2);
     WDM_ETS(12);
     if (pro) {
-        float* w = (float*)(smem + C::SC_OFF);
-        const float* ps = a.scale + (long long)img0 * a.Cin;
-        const float* pf = a.shift + (long long)img0 * a.Cin;
-        for (int i = tid; i < a.Cin; i += C::NTHREADS) { w[i] = ps[i]; w[a.Cin + i] = pf[i]; }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // table visible (also drains the first DMAs: once per workgroup)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NB0 * BCP) : "memory");      // every wave's table piece and this lane's halo pieces landed
         __builtin_amdgcn_sched_barrier(0);
         WDM_ETS(13);
         transform(0);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NB0 - 1) * BCP) : "memory");    // weights (0, 0) in, every lane's transform visible
     __builtin_amdgcn_sched_barrier(0);
     WDM_ETS(7);
     int g = 0;
@@ -298,7 +307,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
             WDM_DMA_SYNC(ACP + BCP);
             issue_b(s + 1, 1, 1);
             mfma_dx(s, 2, 2);
-            if (pro) {
+            if (pro && s + 1 < nslab) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BCP) : "memory");      // the halo slab of s + 1 (this lane's pieces) has landed
                 __builtin_amdgcn_sched_barrier(0);
                 transform(s + 1);
@@ -318,7 +327,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         ++g;
         issue_b(s + 1, 2, (g + 3) & 3);
         mfma_dx(s, 2, g & 3);
-        if (pro) {
+        if (pro && s + 1 < nslab) {             // (the slab fetched past the end is a clamped copy nobody reads)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BCP) : "memory");      // the halo slab of s + 1 (this lane's pieces) has landed
             __builtin_amdgcn_sched_barrier(0);
             transform(s + 1);
