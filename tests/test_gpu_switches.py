@@ -1,0 +1,92 @@
+"""Alternative code paths behind environment switches must agree with the default ones: bit for bit where the arithmetic is the same
+(slab-major weight copies, the 48-wide N tile of the 8x8 kernel -- conv outputs), within the bf16 bound where it is reordered
+(V^T of the attention block as a batched GEMM with the bias behind the softmax; GroupNorm statistics summed per 48- vs 64-wide tile)."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return gpu_util
+
+
+def _with(env, f):
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        return f()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("cin,cout,B", [(768, 768, 5), (512, 768, 2), (1536, 768, 3), (96, 384, 4)])
+def test_8x8_conv_tilings_and_weight_layouts_give_the_same_bits(gu, cin, cout, B):
+    w = gu.seeded((cout, cin, 3, 3), 31) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 32) * 0.1
+    x = gu.seeded((B, cin, 8, 8), 33)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    y = gu.conv(w, b, 0, x, "bf16")                                           # default: 48-wide tile where Cout % 48 == 0, slab-major weights
+    assert rel_linf(y, ref) <= gu.TOL["bf16"]
+    from wavedm_amd import _lib
+
+    def kernels(env):
+        def run():
+            _lib.prof_enable(True)
+            out = gu.conv(w, b, 0, x, "bf16")
+            names = [e["kernel"] for e in _lib.prof_report()]
+            _lib.prof_enable(False)
+            return out, names
+        return _with(env, run)
+
+    seen = set()
+    for env in ({"WDM_WSM": "0"}, {"WDM_DMA8_BN": "64"}, {"WDM_DMA8_BN": "64", "WDM_WSM": "0"}, {"WDM_DMA8": "0"}):
+        out, names = kernels(env)
+        if "WDM_DMA8" in env:                       # the register-staged kernel walks K in another order: same bound, other bits
+            assert rel_linf(out, ref) <= gu.TOL["bf16"] and rel_linf(out, y) <= gu.TOL["bf16"]
+        else:
+            assert torch.equal(y, out), env
+        seen.update(n.split("|")[0] for n in names if n.startswith("conv"))
+    assert any("convdma8" in n and "bn64" in n for n in seen) and any(n.startswith("conv_3x3s1_t8x8") for n in seen), seen      # the switches really switched
+    if cout % 48 == 0:
+        assert any("bn48" in n for n in kernels({})[1])
+
+
+def test_8x8_resblock_tilings_agree(gu):
+    cin = cout = 768
+    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    sd = gu.blk_sd("rb", shapes)
+    x = gu.seeded((3, cin, 8, 8), 5)
+    t = gu.seeded((3, 512), 6)
+    y = gu.resblock(sd, "rb", x, None, t, "bf16")
+    assert torch.equal(y, _with({"WDM_WSM": "0"}, lambda: gu.resblock(sd, "rb", x, None, t, "bf16")))
+    y64 = _with({"WDM_DMA8_BN": "64"}, lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))      # GroupNorm partials in another association
+    assert rel_linf(y, y64) <= 2e-3
+
+
+@pytest.mark.parametrize("C", [512, 256])
+def test_attention_vt_gemm_agrees_with_the_conv_form(gu, C):
+    shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+    for k in ("q", "k", "v", "proj_out"):
+        shapes[k + ".weight"] = (C, C, 1, 1)
+        shapes[k + ".bias"] = (C,)
+    sd = gu.blk_sd("at", shapes)
+    x = gu.seeded((3, C, 16, 16), 9)
+    y = gu.attn(sd, "at", x, "bf16")
+    y_conv = _with({"WDM_ATTN_VT": "0"}, lambda: gu.attn(sd, "at", x, "bf16"))
+    y_f32 = gu.attn(sd, "at", x, "f32")
+    assert not torch.equal(y, y_conv)                     # two different paths really ran
+    assert rel_linf(y, y_f32) <= gu.TOL["bf16"] and rel_linf(y_conv, y_f32) <= gu.TOL["bf16"]

@@ -270,8 +270,8 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
     // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
-    static int vt_gemm = -1;
-    if (vt_gemm < 0) { const char* e = getenv("WDM_ATTN_VT"); vt_gemm = (e && e[0] == '0') ? 0 : 1; }
+    const char* vt_env = getenv("WDM_ATTN_VT");                    // read per call: the tests flip it inside one process
+    const bool vt_gemm = !(vt_env && vt_env[0] == '0');
     const bool v_as_gemm = fused && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
     if (v_as_gemm) {
         if (!c.dry) {
