@@ -1,5 +1,6 @@
-"""The 512 x 128-tile form of the LDS-DMA 3x3 kernel (WDM_DMA32=2, off by default) must produce the bits of the 256 x 128 one:
-same K order, same pixel sets and association per GroupNorm statistics slab (conv_dma_kernel.h)."""
+"""The experimental forms of the LDS-DMA 3x3 kernel (off by default) must produce the bits of the shipped one: the 512 x 128 tile
+(WDM_DMA32=2: same K order, same pixel sets and association per GroupNorm statistics slab) and the K loop that reads the next
+sub-stage's fragments behind its barrier (WDM_DMA_PF=1) -- conv_dma_kernel.h."""
 import os
 
 import pytest
@@ -16,18 +17,18 @@ def gu():
     return gpu_util
 
 
-def _both(f):
-    old = os.environ.get("WDM_DMA32")
+def _both(f, var="WDM_DMA32", on="2"):
+    old = os.environ.get(var)
     try:
-        os.environ["WDM_DMA32"] = "0"
+        os.environ[var] = "0"
         y0 = f()
-        os.environ["WDM_DMA32"] = "2"
+        os.environ[var] = on
         y1 = f()
     finally:
         if old is None:
-            os.environ.pop("WDM_DMA32", None)
+            os.environ.pop(var, None)
         else:
-            os.environ["WDM_DMA32"] = old
+            os.environ[var] = old
     return y0, y1
 
 
@@ -55,3 +56,12 @@ def test_resblock_bits(gu, cin, cout, B, H):
     t = gu.seeded((B, 512), 6)
     y0, y1 = _both(lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))
     assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 128, 2, 32), (256, 128, 3, 64), (96, 256, 2, 32), (512, 512, 3, 16)])
+def test_prefetching_k_loop_bits(gu, cin, cout, B, H):
+    w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 200) * 0.1
+    x = gu.seeded((B, cin, H, H), 316)
+    y0, y1 = _both(lambda: gu.conv(w, b, 0, x, "bf16"), "WDM_DMA_PF", "1")
+    assert torch.equal(y0, y1)

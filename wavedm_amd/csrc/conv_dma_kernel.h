@@ -65,7 +65,9 @@ struct ConvDmaCfgT {
 };
 using ConvDmaCfg = ConvDmaCfgT<4, 2, 4, 4>;
 
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_ = 16, int NRING_ = 4>
+// PF_ = 1: the K loop with its barrier moved into the sub-stage (after two of the three tap rows) and the next sub-stage's fragments read under
+// the third -- see the loop.
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_ = 16, int NRING_ = 4, int PF_ = 0>
 __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ == 8 ? 2 : 1)) void conv_dma_kernel(const ConvArgs a) {
     using C = ConvDmaCfgT<WAVES_M_, WAVES_N_, WM_, WN_, TH_, NRING_>;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
@@ -291,7 +293,66 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     __builtin_amdgcn_sched_barrier(0);
     WDM_ETS(7);
     int g = 0;
-    if (C::NRING == 3) {
+    if constexpr (PF_ != 0) {
+        // One barrier per sub-stage, placed after tap rows 0 and 1.  When a wave passes barrier G every wave has (a) landed its pieces of the weights
+        // of sub-stage G + 1 and (b) finished every LDS read of sub-stage G - 1 (and of G: the tap-row-2 fragments are requested before the barrier),
+        // so behind it the wave refills slot (G - 1) & 3 with the weights of G + 3, requests the fragments sub-stage G + 1 starts with (all its halo
+        // rows, its tap-row-0 weights) and only then issues the tap-row-2 MFMAs of G: the reads' latency and the DMA issue sit under 16 MFMAs
+        // instead of in front of the next sub-stage's first one.  GroupNorm+SiLU of slab s + 1 runs before barrier (s, 2), which publishes it.
+        // In-order DMA queue per wave: [B(G+3)] (+ [A(s+1)] behind it when dx = 0) per sub-stage, hence the counts below.
+        static_assert(C::NRING == 4 && TH == 16, "prefetching loop: 256 x 128 tile, four weight slots");
+        auto load_a = [&](uint4 (&d)[WM + 2], int s_, int dx_) __attribute__((always_inline)) {
+            const char* pa = smem + (s_ & 1) * C::A_BYTES;
+#pragma unroll
+            for (int r = 0; r < WM + 2; ++r) d[r] = *(const uint4*)(pa + a_at(r, dx_));
+        };
+        auto load_b = [&](uint4 (&d)[WN], int slot, int dy) __attribute__((always_inline)) {
+            const char* pb = smem + slot * C::B_SUB;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) d[j] = *(const uint4*)(pb + b_addr[j] + dy * (BN * 64));
+        };
+        auto mm = [&](int dy, const uint4 (&ah_)[WM + 2], const uint4 (&bf_)[WN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], ah_[i + dy], bf_[j]);
+        };
+        uint4 ahC[WM + 2], b0[WN];
+        load_a(ahC, 0, 0);
+        load_b(b0, 0, 0);
+        for (int s = 0; s < nslab; ++s) {
+            if (s >= 1 && s <= 3) WDM_ETS(7 + s);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx, ++g) {
+                uint4 b1[WN], b2[WN], ahN[WM + 2], b0N[WN];
+                __builtin_amdgcn_s_setprio(2);
+                load_b(b1, g & 3, 1);
+                mm(0, ahC, b0);
+                __builtin_amdgcn_s_setprio(1);
+                load_b(b2, g & 3, 2);
+                mm(1, ahC, b1);
+                if (dx == 2 && pro && s + 1 < nslab) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BCP) : "memory");      // this lane's pieces of halo slab s + 1 (only B(g + 2) is younger)
+                    __builtin_amdgcn_sched_barrier(0);
+                    transform(s + 1);
+                }
+                if (dx == 1) WDM_DMA_SYNC(BCP + ACP); else WDM_DMA_SYNC(BCP);       // weights of g + 1 in (younger: B(g + 2), and A(s + 1) when dx = 1)
+                issue_b(s + 1, dx, (g + 3) & 3);
+                if (dx == 0) issue_a(s + 1);
+                if (dx < 2) { load_a(ahN, s, dx + 1); load_b(b0N, (g + 1) & 3, 0); }
+                else if (s + 1 < nslab) { load_a(ahN, s + 1, 0); load_b(b0N, (g + 1) & 3, 0); }
+                __builtin_amdgcn_sched_barrier(0);              // the reads stay in front of the MFMAs that cover them
+                __builtin_amdgcn_s_setprio(0);
+                mm(2, ahC, b2);
+                if (dx < 2 || s + 1 < nslab) {
+#pragma unroll
+                    for (int r = 0; r < WM + 2; ++r) ahC[r] = ahN[r];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) b0[j] = b0N[j];
+                }
+            }
+        }
+    } else if (C::NRING == 3) {
         // ring slot = dx.  Per slab and wave the DMA queue sees  [B(s,2), A(s+1)] [B(s+1,0)] [B(s+1,1)]  (in order), so the counted waits are:
         // before (s,0): all but B(s,1);  before (s,1): all but B(s,2), A(s+1);  before (s,2): all but A(s+1), B(s+1,0);  before the transform of
         // A(s+1): all but B(s+1,0), B(s+1,1).
