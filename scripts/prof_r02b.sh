@@ -14,7 +14,7 @@ echo "Cin,Cout,counter,dispatches,mean_kib" > $OUT
 for SH in "768 768" "1536 768" "1280 768" "512 768"; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/p_pmc
-    SM=1 timeout 90 rocprofv3 --pmc $C -M --output-format csv -d /tmp/p_pmc -- $R/tools/abl_dma8_0 64 $SH > /dev/null 2>&1
+    SM=1 GN=4 timeout 90 rocprofv3 --pmc $C -M --output-format csv -d /tmp/p_pmc -- $R/tools/abl_dma8_0 64 $SH > /dev/null 2>&1
     python3 - "$C" "$SH" >> $OUT <<'P'
 import glob, csv, sys
 c, key = sys.argv[1], sys.argv[2].replace(" ", ",")

@@ -49,8 +49,8 @@ for (cin, cout), v in sh8.items():
                  "ratio": round(hbm / alg, 3)})
 if per8:
     out["kernels"]["conv_dma8_kernel"] = {"hbm_bytes_per_launch": next(p["hbm_bytes_per_launch"] for p in per8), "per_shape": per8,
-                                          "_note": "slab-major weights, 48-wide N tile; the weight tensor (10-21 MB) is re-streamed by each of the 8 XCDs "
-                                                   "(served by the Infinity Cache: XCD-stationary weights measured 10 % slower, DESIGN.md 3.1.1)"}
+                                          "_note": "slab-major weights, 48-wide N tile, N tiles grouped four ways over the XCDs (the library's default, GN=4 in the "
+                                                   "launcher): every XCD streams a quarter of the 10-21 MB weight tensor; ungrouped: 93.7 MB per 768->768 launch"}
 json.dump(out, open(os.path.join(REPO, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
 for k, v in out["kernels"].items():
     print(k, round(v["hbm_bytes_per_launch"] / 1e6, 1), "MB/launch")

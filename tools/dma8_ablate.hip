@@ -32,8 +32,10 @@ int main(int argc, char** argv) {
     if (getenv("SM")) { a.w_tap_stride = (long long)Cout * 32; a.w_row_stride = 32; a.w_slab_stride = 9 * Cout * 32; }      // slab-major weights
     using C = ConvDma8Cfg<BN8>;
     auto kern = conv_dma8_kernel<BN8>;
-    a.mtiles = (B + 1) / 2; a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;
-    const int grid = 8 * a.ntiles * ((a.mtiles + 7) / 8);
+    a.mtiles = (B + 1) / 2; a.ntiles = (Cout + C::BN - 1) / C::BN;
+    const int gn = getenv("GN") ? atoi(getenv("GN")) : 1, gm = 8 / gn;          // N-tile groups per XCD (conv_dispatch.inc: launch_dma8)
+    a.grid_gn = gn;
+    const int grid = 8 * ((a.ntiles + gn - 1) / gn) * ((a.mtiles + gm - 1) / gm);
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, a);
