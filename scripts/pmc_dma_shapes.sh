@@ -25,7 +25,7 @@ SHAPES="64 128 128 1 7
 echo "$SHAPES" | while read H CIN COUT PRO CNT; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/p_pmc
-    timeout 90 rocprofv3 --pmc $C -M --output-format csv -d /tmp/p_pmc -- $R/tools/abl_dma_0 64 $H $CIN $COUT $PRO > /dev/null 2>&1
+    SM=1 timeout 90 rocprofv3 --pmc $C -M --output-format csv -d /tmp/p_pmc -- $R/tools/abl_dma_0 64 $H $CIN $COUT $PRO > /dev/null 2>&1
     python3 - "$C" "$H,$CIN,$COUT,$PRO,$CNT" >> $OUT <<'P'
 import glob, csv, sys
 c, key = sys.argv[1], sys.argv[2]
