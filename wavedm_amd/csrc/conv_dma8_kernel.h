@@ -55,19 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
 
     const int bid = blockIdx.x;
     int mt, nt;
-    {
-        const int gn = a.grid_gn, gm = 8 / gn;
-        const int xcd = bid & 7, seq = bid >> 3;
-        const int xn = xcd % gn, xm = xcd / gn;
-        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
-        if (gn == 1) {
-            if (seq >= mcnt * ncnt) return;
-            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
-        } else {
-            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
-            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
-        }
-    }
+    if (!conv_decode_tile(a, bid, mt, nt)) return;
     const int n0 = nt * BN;
     const int img0 = mt * NI;
 

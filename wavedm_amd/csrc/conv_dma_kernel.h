@@ -83,25 +83,11 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     WDM_ETS(0);
     const int bid = blockIdx.x;
     int mt, nt;
-    {
-        const int gn = a.grid_gn, gm = 8 / gn;
-        const int xcd = bid & 7, seq = bid >> 3;
-        const int xn = xcd % gn, xm = xcd / gn;
-        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
-        if (gn == 1) {
-            if (seq >= mcnt * ncnt) return;
-            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
-        } else {
-            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
-            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
-        }
-    }
+    if (!conv_decode_tile(a, bid, mt, nt)) return;
     const int n0 = nt * BN;
     const int twn = a.Wout / TW;
-    const int tpi = (a.Hout / TH) * twn;
-    const int img0 = mt / tpi;
-    const int tile_in_img = mt - img0 * tpi;
-    const int oy0 = (tile_in_img / twn) * TH, ox0 = (tile_in_img % twn) * TW;
+    int img0, tile_in_img, oy0, ox0;
+    conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
     // ---- DMA plumbing (see conv_gemm_kernel.h for why it is inline asm)

@@ -59,32 +59,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     // workgroup -> (M tile, N tile): same XCD-aware order as conv_kernel
     const int bid = blockIdx.x;
     int mt, nt;
-    {
-        const int gn = a.grid_gn, gm = 8 / gn;
-        const int xcd = bid & 7, seq = bid >> 3;
-        const int xn = xcd % gn, xm = xcd / gn;
-        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
-        if (gn == 1) {
-            if (seq >= mcnt * ncnt) return;
-            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
-        } else {
-            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
-            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
-        }
-    }
+    if (!conv_decode_tile(a, bid, mt, nt)) return;
     const int n0 = nt * BN;
     int img0, oy0, ox0, tile_in_img = 0;
-    if (NI == 1) {
-        const int twn = a.Wout / TW;
-        const int tpi = (a.Hout / TH) * twn;
-        img0 = mt / tpi;
-        const int t = mt - img0 * tpi;
-        tile_in_img = t;
-        oy0 = (t / twn) * TH;
-        ox0 = (t % twn) * TW;
-    } else {
-        img0 = mt * NI; oy0 = 0; ox0 = 0;
-    }
+    if (NI == 1) conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
+    else { img0 = mt * NI; oy0 = 0; ox0 = 0; }
 
     constexpr unsigned OOB = 0xFFFF0000u;
     // ---- per-lane source offsets of this wave's chunks (loop-invariant; the K step is a scalar offset)

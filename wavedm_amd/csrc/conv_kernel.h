@@ -124,6 +124,44 @@ __host__ __device__ inline long long conv_w_img_offset(const ConvArgs& a, int im
 }
 __host__ __device__ inline int conv_x_img(const ConvArgs& a, int img) { return a.x_img_shared ? 0 : a.img_mod ? img % a.img_mod : img; }
 
+// Workgroup -> (M tile, N tile) and tile -> (image, tile of the image) without runtime integer divisions when the divisors are powers of two (they
+// are for every layer of the model): a scalar division by a run-time value is a ~25-instruction dependent chain through v_rcp_iflag_f32, and the ten
+// of them at the head of every conv kernel were most of the 2 400 ticks a workgroup spent before its first DMA (tools/dma_ablate.hip -DWDM_EPI_TS).
+__device__ __forceinline__ void udivmod_fast(int x, int d, int& q, int& r) {        // x >= 0, d > 0
+    if ((d & (d - 1)) == 0) { const int sh = __builtin_ctz(d); q = x >> sh; r = x & (d - 1); }
+    else { q = x / d; r = x - q * d; }
+}
+// false: this workgroup has no tile (the grid is rounded up per XCD)
+__device__ __forceinline__ bool conv_decode_tile(const ConvArgs& a, int bid, int& mt, int& nt) {
+    const int gn = a.grid_gn;
+    const int xcd = bid & 7, seq = bid >> 3;
+    if (gn == 1) {                   // N fastest: the N tiles of one M tile back to back on one XCD
+        const int mcnt = (a.mtiles - xcd + 7) >> 3;
+        if (seq >= mcnt * a.ntiles) return false;
+        int q, r;
+        udivmod_fast(seq, a.ntiles, q, r);
+        nt = r; mt = xcd + 8 * q;
+    } else {                         // M fastest inside an (xm, xn) group of XCDs
+        const int gm = 8 / gn;
+        const int xn = xcd % gn, xm = xcd / gn;
+        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
+        if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return false;
+        int q, r;
+        udivmod_fast(seq, mcnt, q, r);
+        mt = xm + gm * r; nt = xn + gn * q;
+    }
+    return true;
+}
+template <int TH, int TW>
+__device__ __forceinline__ void conv_decode_image(const ConvArgs& a, int mt, int& img0, int& tile_in_img, int& oy0, int& ox0) {
+    const int twn = a.Wout / TW;
+    const int tpi = (a.Hout / TH) * twn;
+    udivmod_fast(mt, tpi, img0, tile_in_img);
+    int ty, tx;
+    udivmod_fast(tile_in_img, twn, ty, tx);
+    oy0 = ty * TH; ox0 = tx * TW;
+}
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -583,33 +621,12 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
     // plain "N tiles of one M tile back to back" order used when the whole weight tensor fits in L2 anyway.
     const int bid = blockIdx.x;
     int mt, nt;
-    {
-        const int gn = a.grid_gn, gm = 8 / gn;
-        const int xcd = bid & 7, seq = bid >> 3;
-        const int xn = xcd % gn, xm = xcd / gn;
-        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
-        if (gn == 1) {               // N fastest
-            if (seq >= mcnt * ncnt) return;
-            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
-        } else {                     // M fastest
-            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
-            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
-        }
-    }
+    if (!conv_decode_tile(a, bid, mt, nt)) return;
     const int n0 = nt * BN;
 
     int img0, oy0, ox0, tile_in_img = 0;
-    if (NI == 1) {
-        const int twn = a.Wout / TW;
-        const int tpi = (a.Hout / TH) * twn;
-        img0 = mt / tpi;
-        const int t = mt - img0 * tpi;
-        tile_in_img = t;
-        oy0 = (t / twn) * TH;
-        ox0 = (t % twn) * TW;
-    } else {
-        img0 = mt * NI; oy0 = 0; ox0 = 0;
-    }
+    if (NI == 1) conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
+    else { img0 = mt * NI; oy0 = 0; ox0 = 0; }
     // origin of the staged input region in source coordinates
     const int iy0 = MODE == MODE_S1 ? oy0 - 1 : MODE == MODE_S2 ? 2 * oy0 : MODE == MODE_UPS ? (oy0 >> 1) - 1 : oy0;
     const int ix0 = MODE == MODE_S1 ? ox0 - 1 : MODE == MODE_S2 ? 2 * ox0 : MODE == MODE_UPS ? (ox0 >> 1) - 1 : ox0;

@@ -52,32 +52,14 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 
     const int bid = blockIdx.x;
     int mt, nt;
-    {
-        const int gn = a.grid_gn, gm = 8 / gn;
-        const int xcd = bid & 7, seq = bid >> 3;
-        const int xn = xcd % gn, xm = xcd / gn;
-        const int ncnt = (a.ntiles - xn + gn - 1) / gn, mcnt = (a.mtiles - xm + gm - 1) / gm;
-        if (gn == 1) {
-            if (seq >= mcnt * ncnt) return;
-            nt = seq % ncnt; mt = xm + gm * (seq / ncnt);
-        } else {
-            if (ncnt <= 0 || mcnt <= 0 || seq >= mcnt * ncnt) return;
-            mt = xm + gm * (seq % mcnt); nt = xn + gn * (seq / mcnt);
-        }
-    }
-    const int phase = nt / a.up4_ntp;
+    if (!conv_decode_tile(a, bid, mt, nt)) return;
+    int phase, ntp;
+    udivmod_fast(nt, a.up4_ntp, phase, ntp);
     const int py = phase >> 1, px = phase & 1;
-    const int n0 = (nt - phase * a.up4_ntp) * BN;
+    const int n0 = ntp * BN;
     int img0, tile_in_img = 0, oy0 = 0, ox0 = 0;
-    if (NI == 1) {
-        const int twn = a.Wout / TW;
-        const int tpi = (a.Hout / TH) * twn;
-        img0 = mt / tpi;
-        tile_in_img = mt - img0 * tpi;
-        oy0 = (tile_in_img / twn) * TH; ox0 = (tile_in_img % twn) * TW;
-    } else {
-        img0 = mt * NI;
-    }
+    if (NI == 1) conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
+    else img0 = mt * NI;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
     typedef int i32x4 __attribute__((ext_vector_type(4)));
