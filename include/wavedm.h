@@ -284,6 +284,12 @@ typedef struct wdm_prof_entry {
 int wdm_prof_enable(int on);
 int wdm_prof_report(wdm_prof_entry* out, int max_entries, int* n_entries);
 
+/* ---- experiment switches ------------------------------------------------------------------------
+ * The WDM_* environment variables (alternative kernels kept for A/B runs; defaults are the measured best) are read once, at
+ * first use -- no launch path calls getenv.  A harness that changes them inside a running process calls this to have them read again.
+ * (No counterpart in the reference: csrc/common.h EnvCfg.) */
+int wdm_env_refresh(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,17 +18,21 @@ def gu():
 
 
 def _both(f, var="WDM_DMA32", on="2"):
+    from wavedm_amd import _lib
     old = os.environ.get(var)
     try:
         os.environ[var] = "0"
+        _lib.env_refresh()
         y0 = f()
         os.environ[var] = on
+        _lib.env_refresh()
         y1 = f()
     finally:
         if old is None:
             os.environ.pop(var, None)
         else:
             os.environ[var] = old
+        _lib.env_refresh()
     return y0, y1
 
 

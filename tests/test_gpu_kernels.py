@@ -87,16 +87,20 @@ def test_subpixel_upsample_equals_nine_tap_kernel(gu, O, B, H):
     x = gu.seeded((B, 96, H, H), 13)
     ref = O.upsample({"c.conv.weight": w, "c.conv.bias": b}, "c", x)
     old = os.environ.get("WDM_UP4")
+    from wavedm_amd import _lib
     try:
         os.environ["WDM_UP4"] = "1"
+        _lib.env_refresh()
         y4 = gu.conv(w, b, 2, x, "bf16")
         os.environ["WDM_UP4"] = "0"
+        _lib.env_refresh()
         y9 = gu.conv(w, b, 2, x, "bf16")
     finally:
         if old is None:
             os.environ.pop("WDM_UP4", None)
         else:
             os.environ["WDM_UP4"] = old
+        _lib.env_refresh()
     e4, e9 = rel_linf(y4, ref), rel_linf(y9, ref)
     assert e4 <= 2e-2 and e9 <= 2e-2 and rel_linf(y4, y9) <= 2e-2, (e4, e9)
     assert not torch.equal(y4, y9)                       # two different kernels really ran

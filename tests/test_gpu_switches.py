@@ -20,9 +20,11 @@ def gu():
 
 
 def _with(env, f):
+    from wavedm_amd import _lib
     old = {k: os.environ.get(k) for k in env}
     try:
         os.environ.update(env)
+        _lib.env_refresh()
         return f()
     finally:
         for k, v in old.items():
@@ -30,6 +32,7 @@ def _with(env, f):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _lib.env_refresh()
 
 
 @pytest.mark.parametrize("cin,cout,B", [(768, 768, 5), (512, 768, 2), (1536, 768, 3), (96, 384, 4)])

@@ -113,6 +113,7 @@ def lib():
         "wdm_cross_attention": (i, [vp, vp, vp, vp, i, i, i, i, vp, vp]),
         "wdm_upsample_add": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
         "wdm_prof_enable": (i, [i]),
+        "wdm_env_refresh": (i, []),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
@@ -133,11 +134,16 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
             "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_dwt_fwd_affine", "wdm_dwt_inv_compose", "wdm_conv2d_direct", "wdm_groupnorm", "wdm_cross_attention", "wdm_upsample_add",
-            "wdm_prof_enable", "wdm_prof_report"]
+            "wdm_prof_enable", "wdm_prof_report", "wdm_env_refresh"]
 
 
 def prof_enable(on: bool):
     check(lib().wdm_prof_enable(1 if on else 0))
+
+
+def env_refresh():
+    """Have the library re-read its WDM_* experiment switches (they are read once, at first use)."""
+    check(lib().wdm_env_refresh())
 
 
 def prof_report():

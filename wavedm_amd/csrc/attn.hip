@@ -7,9 +7,7 @@
 namespace wdm {
 
 bool attn_fused_eligible(int dtype, int N, int C) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("WDM_ATTN_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }      // WDM_ATTN_FUSED=0: the three-launch form (A/B runs)
-    return on && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C;
+    return env_cfg().attn_fused && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C;
 }
 
 int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias) {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include <mutex>
 #include "common.h"
 
 namespace wdm {
@@ -77,9 +78,25 @@ static int alloc_f32(Ctx& c, size_t n, float** p) {
 
 // The sub-pixel Upsample kernel (conv_up4_kernel.h) takes bf16 maps whose LOW-resolution size is a multiple of its 16 x 16 tile, or 8 x 8 (four images per tile); WDM_UP4=0
 // keeps the 9-tap kernel everywhere (A/B runs)
+static EnvCfg g_env;
+static std::once_flag g_env_once;
+void env_cfg_refresh() {
+    EnvCfg c;
+    auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e ? (e[0] == '0' ? 0 : 1) : dflt; };
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    c.up4 = flag("WDM_UP4", 1); c.dma8 = flag("WDM_DMA8", 1); c.dma8_bn64 = num("WDM_DMA8_BN", 0) == 64; c.dma8_gn = num("WDM_DMA8_GN", 4);
+    c.wsm = flag("WDM_WSM", 1); c.dma32 = num("WDM_DMA32", 0); c.dma_pf = num("WDM_DMA_PF", 0) == 1; c.attn_fused = flag("WDM_ATTN_FUSED", 1);
+    c.attn_vt = flag("WDM_ATTN_VT", 1); c.fuse_nin = flag("WDM_FUSE_NIN", 1); c.gn_pass_hw = num("WDM_GN_PASS_HW", 64); c.grid_gn = num("WDM_GRID_GN", 1);
+    c.conv_dma = num("WDM_CONV_DMA", 1) != 0; c.gemm = flag("WDM_GEMM", 1); c.bn128 = flag("WDM_CONV_BN128", 1); c.wgrad_bg = num("WDM_WGRAD_BG", 0);
+    g_env = c;
+}
+const EnvCfg& env_cfg() {
+    std::call_once(g_env_once, env_cfg_refresh);
+    return g_env;
+}
+
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
-    const char* e = getenv("WDM_UP4");                 // read per call (three Upsample convs per UNet pass): tests flip it in-process
-    return !(e && e[0] == '0') && dtype == WDM_BF16 && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+    return env_cfg().up4 && dtype == WDM_BF16 && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
 }
 
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
@@ -177,16 +194,8 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 //    conv repeats the transform: Cout / BN times);
 //  * pass: one elementwise kernel writes act(gn(x)) (and the channel concat) once, the conv runs without prologue.
 // The pass wins where the tensors are small and Cout / BN is large: the 8x8 level (768 channels: 12 N tiles).
-static bool fuse_shortcut_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WDM_FUSE_NIN"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-static int gn_pass_max_hw() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WDM_GN_PASS_HW"); v = e ? atoi(e) : 64; }
-    return v;
-}
+static bool fuse_shortcut_enabled() { return env_cfg().fuse_nin != 0; }
+static int gn_pass_max_hw() { return env_cfg().gn_pass_hw; }
 
 // act(gn([x0|x1])) as one dense tensor
 static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, Tens* out) {
@@ -222,8 +231,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
     // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h unless WDM_DMA8=0)
-    const char* e8 = getenv("WDM_DMA8");
-    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && !(e8 && e8[0] == '0'))) && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
+    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && env_cfg().dma8)) && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
                           conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
     if (w.has_nin && !fuse_nin) {
@@ -270,8 +278,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
     // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
-    const char* vt_env = getenv("WDM_ATTN_VT");                    // read per call: the tests flip it inside one process
-    const bool vt_gemm = !(vt_env && vt_env[0] == '0');
+    const bool vt_gemm = env_cfg().attn_vt != 0;
     const bool v_as_gemm = fused && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
     if (v_as_gemm) {
         if (!c.dry) {

@@ -165,6 +165,29 @@ bool attn_fused_eligible(int dtype, int N, int C);
 // vbias != nullptr: vT was computed without the v bias, which is added to the output instead
 int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr);
 
+// ---- experiment switches (environment), read ONCE -- at first use or when wdm_env_refresh() is called (tests and A/B harnesses that change the
+// environment inside a running process call it); no launch path calls getenv.  Defaults are the measured best.
+struct EnvCfg {
+    int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere
+    int dma8 = 1;         // WDM_DMA8=0: 8x8 convs on the register-staged kernel
+    int dma8_bn64 = 0;    // WDM_DMA8_BN=64: 64-wide N tile on every 8x8 layer
+    int dma8_gn = 4;      // WDM_DMA8_GN=1|2|4|8: N-tile groups per XCD of the 8x8 kernel
+    int wsm = 1;          // WDM_WSM=0: plain weight matrix instead of the slab-major copy
+    int dma32 = 0;        // WDM_DMA32=1|2: 512 x 128 tiles where they fill the chip / wherever the shape allows
+    int dma_pf = 0;       // WDM_DMA_PF=1: K loop that reads the next sub-stage's fragments behind its barrier
+    int attn_fused = 1;   // WDM_ATTN_FUSED=0: attention core as three launches
+    int attn_vt = 1;      // WDM_ATTN_VT=0: V^T by the conv with the channel-major epilogue
+    int fuse_nin = 1;     // WDM_FUSE_NIN=0: 1x1 shortcut as its own GEMM
+    int gn_pass_hw = 64;  // WDM_GN_PASS_HW=<pixels>: largest map that gets the GroupNorm+SiLU pass
+    int grid_gn = 1;      // WDM_GRID_GN=1|2|4|8: XCD tile order of the other conv kernels
+    int conv_dma = 1;     // WDM_CONV_DMA=0: no LDS-DMA 3x3 kernel
+    int gemm = 1;         // WDM_GEMM=0: 1x1 convs on the register-staged kernel
+    int bn128 = 1;        // WDM_CONV_BN128=0: 256 x 64 tiles on the register-staged 3x3 kernel
+    int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
+};
+const EnvCfg& env_cfg();
+void env_cfg_refresh();
+
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 

@@ -38,6 +38,13 @@ int wdm_prof_enable(int on) {
     return WDM_OK;
 }
 
+// Re-reads the WDM_* experiment switches (common.h: EnvCfg); they are otherwise read once, at first use.
+int wdm_env_refresh(void) {
+    env_cfg();                // make sure the first-use initialisation has happened, then overwrite it
+    env_cfg_refresh();
+    return WDM_OK;
+}
+
 // Aggregates and clears the recorded launches.  out[i] rows: launches, total_ms, total_flops, total_bytes.
 int wdm_prof_report(wdm_prof_entry* out, int max_entries, int* n_entries) {
     if (!out || !n_entries) WDM_FAIL(WDM_EINVAL, "wdm_prof_report: null argument");

@@ -544,7 +544,7 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         const long long s_min = (512 + wgs - 1) / wgs;
         for (int d = 1; d <= c.B; ++d)
             if (c.B % d == 0 && c.B / d >= s_min) Bg = d;
-        if (const char* e = getenv("WDM_WGRAD_BG")) { const int v = atoi(e); if (v >= 1 && c.B % v == 0) Bg = v; }
+        { const int v = env_cfg().wgrad_bg; if (v >= 1 && c.B % v == 0) Bg = v; }
     }
     const int S = c.B / Bg;
     int rc = WDM_OK;
