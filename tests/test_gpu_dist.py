@@ -66,3 +66,33 @@ def run_two_ranks(tmp_path, backend):
 
 def test_two_ranks_match_single_process(tmp_path):
     run_two_ranks(tmp_path, "gloo")
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver's scaling leg may use) re-executes itself under
+    torch.distributed.run and prints one JSON line with the rccl sub-record; gloo backend so that both ranks share this box's GPU."""
+    import json
+    repo = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["WAVEDM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 128 and rec["config"]["outputs_finite"]
+    assert rec["rccl"]["rccl_ranks"] == 2 and rec["rccl"]["weight_broadcast_s"] is not None
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_bench_refuses_more_gpus_than_present():
+    """Asking for more RCCL ranks than the node has devices answers with one JSON line (value null, error text) and a non-zero exit."""
+    import json
+    repo = os.path.dirname(HERE)
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WAVEDM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=300, cwd=repo)
+    assert r.returncode != 0
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["value"] is None and "GPU" in rec["error"]
