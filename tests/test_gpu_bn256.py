@@ -1,0 +1,68 @@
+"""The 256-column tilings of the LDS-DMA 3x3 kernel (conv_dma256_kernel.h: 256 x 256 and 128 x 256 output tiles) must produce the BITS of the
+256 x 128 tile (conv_dma_kernel.h): same K order per pixel, same pixel sets and association per GroupNorm statistics slab -- the launcher picks
+a tiling by workgroup count, so an image's result must not depend on it.  Checked through the C ABI on single convs (vs torch as well) and on
+whole ResnetBlocks (statistics from the epilogue, temb, residual, fused 1x1 shortcut over a concat input)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_util
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return gpu_util
+
+
+def _modes(f, modes=("0", "2", "3", "1")):
+    from wavedm_amd import _lib
+    old = os.environ.get("WDM_BN256")
+    out = []
+    try:
+        for m in modes:
+            os.environ["WDM_BN256"] = m
+            _lib.env_refresh()
+            out.append(f())
+    finally:
+        if old is None:
+            os.environ.pop("WDM_BN256", None)
+        else:
+            os.environ["WDM_BN256"] = old
+        _lib.env_refresh()
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 256, 2, 32), (256, 256, 3, 32), (768, 256, 1, 32), (512, 512, 3, 16), (1280, 512, 2, 16), (96, 256, 1, 48)])
+def test_conv_bits(gu, cin, cout, B, H):
+    w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 200) * 0.1
+    x = gu.seeded((B, cin, H, H), 316)
+    ys = _modes(lambda: gu.conv(w, b, 0, x, "bf16"))
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    assert float((ys[1] - ref).abs().max() / ref.abs().max()) <= gu.TOL["bf16"]
+
+
+@pytest.mark.parametrize("c0,c1,cout,B,H", [(256, 0, 256, 2, 32), (256, 256, 256, 2, 32), (512, 256, 256, 1, 32), (512, 0, 512, 3, 16), (512, 512, 512, 2, 16),
+                                            (768, 512, 512, 1, 16)])
+def test_resblock_bits(gu, c0, c1, cout, B, H):
+    """conv1 (prologue over the concat, temb, statistics) and conv2 (statistics, residual or the fused 1x1 shortcut) through every tiling."""
+    cin = c0 + c1
+    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    if cin != cout:
+        shapes["nin_shortcut.weight"] = (cout, cin, 1, 1)
+        shapes["nin_shortcut.bias"] = (cout,)
+    sd = gu.blk_sd("rb", shapes)
+    x0 = gu.seeded((B, c0, H, H), 5)
+    x1 = gu.seeded((B, c1, H, H), 7) if c1 else None
+    t = gu.seeded((B, 512), 6)
+    ys = _modes(lambda: gu.resblock(sd, "rb", x0, x1, t, "bf16"))
+    assert torch.isfinite(ys[0]).all()
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y)
