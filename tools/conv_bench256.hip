@@ -13,6 +13,7 @@
 #include <vector>
 #include "conv_dma_kernel.h"
 #include "conv_dma256_kernel.h"
+#include "conv_dmap_kernel.h"
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -22,7 +23,7 @@ static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 
 struct Shape { int B, H, Cin, Cout, pro, res, sc; };      // sc: channels of the fused 1x1 shortcut's input (0 = none)
 typedef void (*kern_t)(const ConvArgs);
-struct Variant { const char* name; kern_t kern; int lds, th, bn; };
+struct Variant { const char* name; kern_t kern; int lds, th, bn, persist; };
 
 static float time_kernel(const Variant& v, int grid, const ConvArgs& a, int it) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -36,6 +37,7 @@ static float time_kernel(const Variant& v, int grid, const ConvArgs& a, int it) 
 
 int main(int argc, char** argv) {
     std::vector<Shape> shapes = {
+        {64, 64, 128, 128, 1, 1, 0}, {64, 64, 128, 128, 1, 0, 256}, {64, 64, 256, 128, 1, 0, 0}, {64, 64, 384, 128, 1, 0, 0}, {64, 64, 96, 128, 0, 0, 0}, {9, 64, 128, 128, 1, 1, 0}, {17, 32, 64, 128, 1, 0, 128},
         {64, 32, 256, 256, 1, 0, 512}, {64, 32, 256, 256, 1, 1, 0}, {64, 32, 768, 256, 1, 0, 0}, {64, 32, 512, 256, 1, 0, 0}, {64, 32, 384, 256, 1, 0, 0},
         {64, 32, 128, 256, 1, 0, 0}, {64, 16, 512, 512, 1, 0, 1024}, {64, 16, 512, 512, 1, 1, 0}, {64, 16, 1280, 512, 1, 0, 0}, {64, 16, 1024, 512, 1, 0, 0},
         {64, 16, 768, 512, 1, 0, 0}, {64, 16, 256, 512, 1, 0, 0}, {3, 16, 512, 512, 1, 1, 0}, {2, 32, 128, 256, 1, 0, 192}, {5, 48, 64, 256, 0, 0, 0},
@@ -46,10 +48,14 @@ int main(int argc, char** argv) {
     using C256 = ConvDma256Cfg<4, 2, 4, 8, 16>;
     using C256h = ConvDma256Cfg<2, 4, 4, 4, 8>;
     std::vector<Variant> vars = {
-        {"t256x128", conv_dma_kernel<4, 2, 4, 4>, C128::LDS_BYTES, 16, 128},
-        {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16>, C256::LDS_BYTES, 16, 256},
-        {"t128x256", conv_dma256_kernel<2, 4, 4, 4, 8>, C256h::LDS_BYTES, 8, 256},
+        {"t256x128", conv_dma_kernel<4, 2, 4, 4>, C128::LDS_BYTES, 16, 128, 0},
+        {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16>, C256::LDS_BYTES, 16, 256, 0},
+        {"t128x256", conv_dma256_kernel<2, 4, 4, 4, 8>, C256h::LDS_BYTES, 8, 256, 0},
+        {"persist2", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
+        {"persist1", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
     };
+    if (getenv("ONLY")) { std::vector<Variant> keep = {vars[0]}; for (size_t i = 1; i < vars.size(); ++i) if (strstr(getenv("ONLY"), vars[i].name)) keep.push_back(vars[i]); vars = keep; }
+    const int NCU = getenv("NCU") ? atoi(getenv("NCU")) : 256;
     const int NV = (int)vars.size();
     for (auto& v : vars) CK(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
     int bad_total = 0;
@@ -112,8 +118,11 @@ int main(int argc, char** argv) {
             aa[i] = a; aa[i].y = y[i]; aa[i].stats = st[i];
             aa[i].mtiles = B * (H / vars[i].th) * (H / 16); aa[i].ntiles = (Cout + vars[i].bn - 1) / vars[i].bn; aa[i].grid_gn = 1;
             grid[i] = 8 * aa[i].ntiles * ((aa[i].mtiles + 7) / 8);
+            if (vars[i].persist && grid[i] > NCU) grid[i] = NCU;
         }
-        for (int v = 0; v < NV; ++v) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(512), vars[v].lds, 0, aa[v]);
+        std::vector<int> skip(NV, 0);
+        for (int v = 0; v < NV; ++v) skip[v] = vars[v].bn == 256 && Cout % 256 != 0;
+        for (int v = 0; v < NV; ++v) if (!skip[v]) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(512), vars[v].lds, 0, aa[v]);
         CK(hipDeviceSynchronize());
         std::vector<unsigned short> h0(ny), h1(ny);
         std::vector<unsigned> s0((size_t)B * nslab * Cout * 4), s1(s0.size());
@@ -123,18 +132,19 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < ny; ++i) { amax = fmax(amax, fabs(bf2f(h0[i]))); csum += bf2f(h0[i]) * (double)((i % 251) + 1); }
         std::vector<size_t> nbad(NV, 0), nbad_s(NV, 0);
         for (int v = 1; v < NV; ++v) {
+            if (skip[v]) continue;
             CK(hipMemcpy(h1.data(), y[v], ny * 2, hipMemcpyDeviceToHost));
             CK(hipMemcpy(s1.data(), st[v], s1.size() * 4, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < ny; ++i) if (h0[i] != h1[i]) ++nbad[v];
-            for (size_t i = 0; i < s0.size(); ++i) if (s0[i] != s1[i]) ++nbad_s[v];
+            for (size_t i = 0; i < s0.size(); ++i) if (s0[i] != s1[i]) { if (nbad_s[v] < 6 && getenv("DUMP")) { float f0, f1; memcpy(&f0, &s0[i], 4); memcpy(&f1, &s1[i], 4); const size_t e = i / 4; printf("   %s stats[%zu] img %zu slab %zu ch %zu word %zu: %.9g vs %.9g\n", vars[v].name, i, e / ((size_t)nslab * Cout), (e / Cout) % nslab, e % Cout, i % 4, f0, f1); } ++nbad_s[v]; }
             bad_total += (nbad[v] != 0) + (nbad_s[v] != 0);
         }
         std::vector<float> t(NV, 1e9f);
         for (int round = 0; round < rounds; ++round)
-            for (int v = 0; v < NV; ++v) t[v] = fminf(t[v], time_kernel(vars[v], grid[v], aa[v], iters));
+            for (int v = 0; v < NV; ++v) if (!skip[v]) t[v] = fminf(t[v], time_kernel(vars[v], grid[v], aa[v], iters));
         const double fl = 2.0 * B * H * (double)H * Cout * (9.0 * Cin + sh.sc);
         printf("B=%2d %2dx%-2d %4d->%-4d pro=%d res=%d sc=%-4d amax %.2f csum %.6g |", B, H, H, Cin, Cout, sh.pro, sh.res, sh.sc, amax, csum);
-        for (int v = 0; v < NV; ++v) printf(" %s wg %4d %6.1f us %5.0f TF (bad %zu / %zu) |", vars[v].name, grid[v], t[v], fl / t[v] / 1e6, nbad[v], nbad_s[v]);
+        for (int v = 0; v < NV; ++v) if (!skip[v]) printf(" %s wg %4d %6.1f us %5.0f TF (bad %zu / %zu) |", vars[v].name, grid[v], t[v], fl / t[v] / 1e6, nbad[v], nbad_s[v]);
         printf("\n");
         CK(hipFree(x0)); if (x1) CK(hipFree(x1)); CK(hipFree(w)); CK(hipFree(wsm)); CK(hipFree(res)); CK(hipFree(sc)); CK(hipFree(shf)); CK(hipFree(bias)); CK(hipFree(sbias)); CK(hipFree(temb));
         if (sx) { CK(hipFree(sx)); CK(hipFree(sw)); }

@@ -185,6 +185,8 @@ struct EnvCfg {
     int bn128 = 1;        // WDM_CONV_BN128=0: 256 x 64 tiles on the register-staged 3x3 kernel
     int bn256 = 1;        // WDM_BN256=0|1|2|3: 256-column LDS-DMA 3x3 tiles never / by workgroup count / 256-pixel tile always / 128-pixel tile always
     int bn256_half = 0;   // WDM_BN256_HALF=1: 128 x 256 tiles where 256 x 256 ones are too few (stand-alone +4-8 %, inside the model -10 %: cold weights, one sub-stage of lead)
+    int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
+    int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
 };
 const EnvCfg& env_cfg();

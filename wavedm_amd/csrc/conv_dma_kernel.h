@@ -81,6 +81,9 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     const int wave_m = wave / C::WAVES_N, wave_n = wave % C::WAVES_N;
 
     WDM_ETS(0);
+#ifdef WDM_WG_CLOCK      // tools/dmap_timeline.hip: per-workgroup s_memrealtime (100 MHz) and s_memtime at entry and exit
+    if (threadIdx.x == 0) { a.ts[512 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); a.ts[512 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime(); }
+#endif
     const int bid = blockIdx.x;
     int mt, nt;
     if (!conv_decode_tile(a, bid, mt, nt)) return;
@@ -462,6 +465,9 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     static_assert(WM == TH / 4, "four wave rows");
     if constexpr (TH == 16) {
         conv_epilogue<T, 16, TW, 4, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+#ifdef WDM_WG_CLOCK
+        if (threadIdx.x == 0) { a.ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); a.ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }
+#endif
     } else {
         // each 16-row half of the tile is a 16 x 16 tile of the small configuration (see the header): wave_m 0, 1 own the upper half, 2, 3 the lower
         // one; a wave's 128 rows go in two passes of 64 (one statistics slab each) through the same 64 x 68 LDS tile

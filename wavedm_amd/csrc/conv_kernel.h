@@ -132,7 +132,8 @@ __device__ __forceinline__ void udivmod_fast(int x, int d, int& q, int& r) {    
     else { q = x / d; r = x - q * d; }
 }
 // false: this workgroup has no tile (the grid is rounded up per XCD)
-__device__ __forceinline__ bool conv_decode_tile(const ConvArgs& a, int bid, int& mt, int& nt) {
+template <class AT>
+__device__ __forceinline__ bool conv_decode_tile(const AT& a, int bid, int& mt, int& nt) {      // AT: ConvArgs in any address space
     const int gn = a.grid_gn;
     const int xcd = bid & 7, seq = bid >> 3;
     if (gn == 1) {                   // N fastest: the N tiles of one M tile back to back on one XCD
@@ -152,8 +153,8 @@ __device__ __forceinline__ bool conv_decode_tile(const ConvArgs& a, int bid, int
     }
     return true;
 }
-template <int TH, int TW>
-__device__ __forceinline__ void conv_decode_image(const ConvArgs& a, int mt, int& img0, int& tile_in_img, int& oy0, int& ox0) {
+template <int TH, int TW, class AT>
+__device__ __forceinline__ void conv_decode_image(const AT& a, int mt, int& img0, int& tile_in_img, int& oy0, int& ox0) {
     const int twn = a.Wout / TW;
     const int tpi = (a.Hout / TH) * twn;
     udivmod_fast(mt, tpi, img0, tile_in_img);
@@ -297,9 +298,18 @@ __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { re
 #endif
 // `write_pass(ep, jp)` puts the wave's accumulators of the 16-column fragments [jp, jp + NJ) into its fp32 tile ep[row][ESTR] (row = pixel of the wave
 // tile in row-major order); it is the only part that knows the MFMA C layout (16x16 fragments below, 32x32 ones in conv_pp_kernel.h).
-template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass>
-__device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
-                                                int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
+// `hook()` runs once, at the end of the first pass (every value that pass loaded -- bias, temb, residual -- has been consumed, its stores are issued):
+// the persistent kernel issues the next tile's first DMAs there.  Earlier, the compiler's waits for the epilogue's own loads would also wait for the
+// DMAs queued behind them (one in-order counter); the remaining passes and the statistics then run while the DMAs are in flight.
+// entry_barrier = false: the caller has already closed the main loop with a workgroup barrier (and must not have its DMA queue drained by
+// __syncthreads(), which waits vmcnt(0) while an LDS-DMA is pending).
+struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
+// CANON: the statistics of a slab are summed in ascending order of its 16-row chunks whatever NJ is -- the association of the one-pass form
+// (NJ = WN = 4: one lane walks all rows of a column) -- so that a multi-pass epilogue writes the bits of the one-pass one.
+template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
+__device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
+                                                int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
+                                                bool entry_barrier = true) {
     constexpr int VEC = TI<T>::VEC;
     constexpr int ES = 16 / VEC;                           // bytes per element of T
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);   // 16-column fragments per pass (NJ_ = WN: one pass, whole 128-byte rows per wave)
@@ -349,7 +359,7 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
     for (int jp = 0; jp < WN; jp += NJ) {
         // The fp32 tile is private to the wave, and the LDS executes one wave's instructions in order: only the hand-over from the
         // main loop (other waves may still read the operand images this tile overlays) needs the workgroup barrier.
-        if (jp == 0) { WDM_ETS(1); __syncthreads(); WDM_ETS(2); }
+        if (jp == 0) { WDM_ETS(1); if (entry_barrier) __syncthreads(); WDM_ETS(2); }
         else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         if (active) write_pass(ep, jp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -464,6 +474,7 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                 }
             }
             WDM_ETS(4);
+            if (jp == 0) hook();
             if (do_stats) {
                 // wave-local: the LDS executes one wave's instructions in order, so the column reads below see the
                 // write-backs above; the fence only stops the compiler from reordering them
@@ -482,15 +493,31 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                 float s1 = 0.f, s2 = 0.f;
                 constexpr int CH = RPP < 16 ? RPP : 16;
                 static_assert(RPP % CH == 0, "statistics rows per lane must be a multiple of the chunk");
+                constexpr int NCH = RPP / CH;
+                float cs1[NCH], cs2[NCH];
 #pragma unroll
-                for (int ch = 0; ch < RPP / CH; ++ch) {
+                for (int ch = 0; ch < NCH; ++ch) {
                     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-                    for (int r = 0; r < CH; ++r) { const float d = ep[(r0 + ch * CH + r) * ESTR + col] - K; c1 += d; c2 += d * d; }
+                    for (int r = 0; r < CH; ++r) { const float d = ep[(r0 + ch * CH + r) * ESTR + col] - K; c1 += d; c2 = __builtin_fmaf(d, d, c2); }      // explicit fma: every tiling rounds alike
+                    cs1[ch] = c1; cs2[ch] = c2;
                     if (ch == 0) { s1 = c1; s2 = c2; } else { s1 += c1; s2 += c2; }
                 }
+                if (CANON && SROWS / RPP > 1) {
+                    // every lane walks the slab's chunks in row order, fetching the other lane groups' chunk sums (K is the slab's, the same in all of them)
+                    constexpr int GPS = SROWS / RPP;                          // lane groups per slab
+                    const int base = (part / GPS) * GPS;
 #pragma unroll
-                for (int off = ECOLS; off < ECOLS * (SROWS / RPP); off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                    for (int pg = 0; pg < GPS; ++pg)
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch) {
+                            const float v1 = __shfl(cs1[ch], col + ECOLS * (base + pg)), v2 = __shfl(cs2[ch], col + ECOLS * (base + pg));
+                            if (pg == 0 && ch == 0) { s1 = v1; s2 = v2; } else { s1 += v1; s2 += v2; }
+                        }
+                } else {
+#pragma unroll
+                    for (int off = ECOLS; off < ECOLS * (SROWS / RPP); off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                }
                 // all rows of a wave tile belong to one image
                 const int m0 = wave_m * EROWS + srow;
                 const int img_g = img0 + m0 / (TH * TW);
@@ -530,13 +557,15 @@ __device__ __forceinline__ void conv_epilogue_w(const ConvArgs& a, WritePass&& w
                     }
                 }
             }
+            if (jp == 0) hook();
         }
     }
 }
 
-template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
-                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0) {
+template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
+__device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
+                                              int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
+                                              bool entry_barrier = true) {
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
     constexpr int ESTR = 16 * NJ + 4;
@@ -547,7 +576,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[WM
             for (int i = 0; i < WM; ++i)
                 *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
-    conv_epilogue_w<T, TH, TW, WM, WN, NJ_>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
+    conv_epilogue_w<T, TH, TW, WM, WN, NJ_, decltype(write_pass)&, Hook, CANON>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, entry_barrier);
     WDM_ETS(5);
 #ifdef WDM_EPI_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -339,25 +339,34 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     const int gw = C / 32, C1 = C - C0;
     const int lane = threadIdx.x;
     const int cg0 = g * gw;
-    const double kg = (cg0 < C0) ? (double)st0[((long long)b * nslab0) * C0 + cg0].x : (double)st1[((long long)b * nslab1) * C1 + (cg0 - C0)].x;
+    // ONE memory round trip: the group's pivot (first channel, slab 0), the first batch of partials and this lane's gamma / beta are all requested before
+    // anything is used (the kernel is one wave per (group, image): its time is dependent-load latency -- three round trips in a row before).  The
+    // accumulation order per lane (ascending item index) and the shuffle tree are unchanged, so the result is bit-identical.
+    const float4* kp = (cg0 < C0) ? &st0[((long long)b * nslab0) * C0 + cg0] : &st1[((long long)b * nslab1) * C1 + (cg0 - C0)];
+    const float kgf = kp->x;
     double S1 = 0.0, S2 = 0.0;
     // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
     const int n0c = max(0, min(C0 - cg0, gw));        // channels of this group that live in tensor 0
     const int items0 = n0c * nslab0, items = items0 + (gw - n0c) * nslab1;
-    // Up to four partials per lane, all loaded before any is used: the kernel is one wave per (group, image) and its time is the
-    // dependent-load latency of this loop (rocprofv3: 5.5 us average with one load in flight per lane).  The accumulation order per lane
-    // (ascending item index) and the shuffle tree are unchanged, so the result is bit-identical.
     auto load_item = [&](int it) __attribute__((always_inline)) -> float4 {
         if (it < items0) { const int ci = it / nslab0, sl = it % nslab0; return st0[((long long)b * nslab0 + sl) * C0 + cg0 + ci]; }
         const int j = it - items0; const int ci = n0c + j / nslab1, sl = j % nslab1;
         return st1[((long long)b * nslab1 + sl) * C1 + (cg0 + ci - C0)];
     };
+    float4 v0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (lane + 64 * u < items) v0[u] = load_item(lane + 64 * u);
+    float gam0 = 0.f, bet0 = 0.f;
+    if (lane < gw) { gam0 = gamma[cg0 + lane]; bet0 = beta[cg0 + lane]; }
+    const double kg = (double)kgf;
     auto accumulate = [&](const float4& v) __attribute__((always_inline)) {
         const double n = (double)v.w, d = (double)v.x - kg, a1 = (double)v.y, a2 = (double)v.z;
         S1 += a1 + n * d;
         S2 += a2 + 2.0 * d * a1 + n * d * d;
     };
-    for (int it0 = lane; it0 < items; it0 += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (lane + 64 * u < items) accumulate(v0[u]);
+    for (int it0 = lane + 256; it0 < items; it0 += 256) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (it0 + 64 * u < items) v[u] = load_item(it0 + 64 * u);
@@ -378,9 +387,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     if (mean_rstd != nullptr && lane == 0) { mean_rstd[((long long)b * 32 + g) * 2] = mean; mean_rstd[((long long)b * 32 + g) * 2 + 1] = rstd; }
     for (int ci = lane; ci < gw; ci += 64) {
         const int c = cg0 + ci;
-        const float sc = rstd * gamma[c];
+        const float gm = ci < 64 ? gam0 : gamma[c], bt = ci < 64 ? bet0 : beta[c];
+        const float sc = rstd * gm;
         scale[(long long)b * C + c] = sc * premul;
-        shift[(long long)b * C + c] = (beta[c] - mean * sc) * premul;
+        shift[(long long)b * C + c] = (bt - mean * sc) * premul;
     }
 }
 
