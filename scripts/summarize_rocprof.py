@@ -27,6 +27,13 @@ def short(name: str) -> str:
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         return f"convdma_3x3s1_t16x16x1_bn128w{a[0] * a[1]}_bf16"
+    m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)", name)
+    if m:
+        a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
+        return f"convdma_3x3s1_t{a[4]}x16x1_bn256w8_bf16"
+    m = re.search(r"conv_dmap_kernelILb(\d)E", name)
+    if m:
+        return "convdmap_3x3s1_t16x16x1_bn128w8_bf16" + ("_2pass" if m.group(1) == "1" else "")
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E", name)
     if m:
         return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn128w8_bf16"

@@ -106,3 +106,16 @@ def test_persistent_bits(gu, c0, c1, cout, B, H):
     assert torch.isfinite(ys[0]).all()
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(256, 256, 2, 32), (512, 512, 3, 16), (256, 512, 1, 48)])
+def test_upsample_conv_bits(gu, cin, cout, B, H):
+    """Sub-pixel Upsample conv (conv_up4_kernel.h): 256-column tiles == 128-column ones, and both follow torch's nearest x2 + conv3x3."""
+    w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 200) * 0.1
+    x = gu.seeded((B, cin, H, H), 316)
+    ys = _modes(lambda: gu.conv(w, b, 2, x, "bf16"), modes=("0", "2", "1"))
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    assert float((ys[1] - ref).abs().max() / ref.abs().max()) <= gu.TOL["bf16"]

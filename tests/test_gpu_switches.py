@@ -93,3 +93,28 @@ def test_attention_vt_gemm_agrees_with_the_conv_form(gu, C):
     y_f32 = gu.attn(sd, "at", x, "f32")
     assert not torch.equal(y, y_conv)                     # two different paths really ran
     assert rel_linf(y, y_f32) <= gu.TOL["bf16"] and rel_linf(y_conv, y_f32) <= gu.TOL["bf16"]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_fused_groupnorm_pass_gives_the_bits_of_finalize_plus_apply(gu, dtype):
+    """k_gn_finalize_apply (one launch: the 8x8 ResnetBlocks' GroupNorm+SiLU passes incl. the channel concat, the AttnBlocks' GroupNorm) against
+    gn_finalize + gn_apply per tensor (WDM_GN_FUSED=0): the same reduction order and the same elementwise arithmetic, hence the same bits."""
+    c0, c1, cout = 768, 768, 768
+    cin = c0 + c1
+    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,),
+              "nin_shortcut.weight": (cout, cin, 1, 1), "nin_shortcut.bias": (cout,)}
+    sd = gu.blk_sd("rb", shapes)
+    x0, x1, t = gu.seeded((3, c0, 8, 8), 5), gu.seeded((3, c1, 8, 8), 7), gu.seeded((3, 512), 6)
+    y = _with({"WDM_GN_FUSED": "1"}, lambda: gu.resblock(sd, "rb", x0, x1, t, dtype))
+    y_sep = _with({"WDM_GN_FUSED": "0"}, lambda: gu.resblock(sd, "rb", x0, x1, t, dtype))
+    assert torch.isfinite(y).all() and torch.equal(y, y_sep)
+    for C, H in ((512, 16), (768, 8), (64, 8)):
+        ash = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            ash[k + ".weight"] = (C, C, 1, 1)
+            ash[k + ".bias"] = (C,)
+        asd = gu.blk_sd("at", ash)
+        x = gu.seeded((2, C, H, H), 9)
+        a = _with({"WDM_GN_FUSED": "1"}, lambda: gu.attn(asd, "at", x, dtype))
+        assert torch.equal(a, _with({"WDM_GN_FUSED": "0"}, lambda: gu.attn(asd, "at", x, dtype)))

@@ -88,7 +88,7 @@ void env_cfg_refresh() {
     c.wsm = flag("WDM_WSM", 1); c.dma32 = num("WDM_DMA32", 0); c.dma_pf = num("WDM_DMA_PF", 0) == 1; c.attn_fused = flag("WDM_ATTN_FUSED", 1);
     c.attn_vt = flag("WDM_ATTN_VT", 1); c.fuse_nin = flag("WDM_FUSE_NIN", 1); c.gn_pass_hw = num("WDM_GN_PASS_HW", 64); c.grid_gn = num("WDM_GRID_GN", 1);
     c.conv_dma = num("WDM_CONV_DMA", 1) != 0; c.gemm = flag("WDM_GEMM", 1); c.bn128 = flag("WDM_CONV_BN128", 1); c.wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
+    c.gn_fused = flag("WDM_GN_FUSED", 0); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
     c.bn256 = num("WDM_BN256", 1); c.bn256_half = flag("WDM_BN256_HALF", 0);
     g_env = c;
 }
@@ -199,19 +199,44 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 static bool fuse_shortcut_enabled() { return env_cfg().fuse_nin != 0; }
 static int gn_pass_max_hw() { return env_cfg().gn_pass_hw; }
 
-// act(gn([x0|x1])) as one dense tensor
-static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, Tens* out) {
+// partial statistics of x (its producer's, or a pass over the tensor): *tmp is what the caller has to free afterwards
+static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tmp) {
+    *tmp = nullptr;
+    if (x.stats) { *st = x.stats; *ns = x.nslab; return WDM_OK; }
+    *ns = gn_default_nslab(x.H * x.W);
+    *tmp = (float*)c.ar->alloc(gn_stats_bytes(c.B, *ns, x.C));
+    if (!*tmp) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
+    *st = *tmp;
+    if (!c.dry) WDM_TRY(k_gn_partial(x, c.B, *tmp, *ns, c.dtype, c.s));
+    return WDM_OK;
+}
+
+// act(gn([x0|x1])) as one dense tensor (silu != 0: with SiLU) -- one launch (k_gn_finalize_apply), or finalize + apply per tensor with WDM_GN_FUSED=0
+static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int silu, Tens* out) {
+    const int C = x0.C + (x1 ? x1->C : 0);
+    if (env_cfg().gn_fused && C <= 4096) {
+        float *st0 = nullptr, *st1 = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
+        int ns0 = 0, ns1 = 1;
+        WDM_TRY(gn_partials_of(c, x0, &st0, &ns0, &tmp0));
+        if (x1) WDM_TRY(gn_partials_of(c, *x1, &st1, &ns1, &tmp1));
+        WDM_TRY(alloc_tens(c, C, x0.H, x0.W, out));
+        int rc = WDM_OK;
+        if (!c.dry) rc = k_gn_finalize_apply(c.B, x0, x1, st0, ns0, st1, ns1, nw, 1e-6f, silu, out->p, c.dtype, c.s);
+        if (tmp0) c.ar->free(tmp0);
+        if (tmp1) c.ar->free(tmp1);
+        return rc;
+    }
     float *sc, *sh;
     WDM_TRY(run_gn(c, nw, x0, x1, 0, &sc, &sh));
-    const int C = x0.C + (x1 ? x1->C : 0);
     WDM_TRY(alloc_tens(c, C, x0.H, x0.W, out));
     if (!c.dry) {
-        WDM_TRY(k_gn_apply(x0, c.B, sc, sh, C, out->p, C, 0, 1, c.dtype, c.s));
-        if (x1) WDM_TRY(k_gn_apply(*x1, c.B, sc + x0.C, sh + x0.C, C, out->p, C, x0.C, 1, c.dtype, c.s));
+        WDM_TRY(k_gn_apply(x0, c.B, sc, sh, C, out->p, C, 0, silu, c.dtype, c.s));
+        if (x1) WDM_TRY(k_gn_apply(*x1, c.B, sc + x0.C, sh + x0.C, C, out->p, C, x0.C, silu, c.dtype, c.s));
     }
     c.ar->free(sc); c.ar->free(sh);
     return WDM_OK;
 }
+static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, Tens* out) { return materialize_gn(c, nw, x0, x1, 1, out); }
 
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
@@ -265,12 +290,8 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     if (x.C != C) WDM_FAIL(WDM_EINVAL, "attn: input has %d channels, block expects %d", x.C, C);
     if (N % 64 || N > 512) WDM_FAIL(WDM_EINVAL, "attn: %d tokens unsupported (multiple of 64, <= 512)", N);
     const size_t es = dsize(c.dtype);
-    float *sc, *sh;
-    WDM_TRY(run_gn(c, w.n, x, nullptr, 0, &sc, &sh));
     Tens hn;
-    WDM_TRY(alloc_tens(c, C, x.H, x.W, &hn));
-    if (!c.dry) WDM_TRY(k_gn_apply(x, c.B, sc, sh, C, hn.p, C, 0, 0, c.dtype, c.s));
-    c.ar->free(sc); c.ar->free(sh);
+    WDM_TRY(materialize_gn(c, w.n, x, nullptr, 0, &hn));
 
     Tens qk;
     WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));   // [B][N][2C]

@@ -19,27 +19,30 @@ namespace wdm {
 
 // TILE x TILE low-resolution pixels of NI images per workgroup: (16, 1) for maps that are multiples of 16, (8, 4) for 8 x 8 maps
 // (one image per wave row: the 64 rows of a wave tile are one image)
-template <int TILE, int NI_>
+// WN_ = 8: 256 output channels per workgroup (8 waves of 64 x 128; conv_dma256_kernel.h's argument: half the workgroups, prologues and halo fetches per
+// MFMA, 64 instead of 32 MFMAs per wave between two barriers) -- the same K order and statistics slabs, hence the same bits as WN_ = 4
+template <int TILE, int NI_, int WN_ = 4>
 struct ConvUp4Cfg {
-    static constexpr int TH = TILE, TW = TILE, NI = NI_, WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4;
-    static constexpr int NWAVES = 8, NTHREADS = 512, BN = 128, BK = 32;
+    static constexpr int TH = TILE, TW = TILE, NI = NI_, WAVES_M = 4, WAVES_N = 2, WM = 4, WN = WN_;
+    static constexpr int NWAVES = 8, NTHREADS = 512, BN = 16 * WN * WAVES_N, BK = 32;
     static_assert(TH * TW * NI == 256 && (NI == 1 || TH * TW == 16 * WM), "256-row tile; multi-image tiles: one image per wave row");
     static constexpr int PH = TH + 2, PW = TW + 2, RS = (PW + 7) / 8 * 8;
     static constexpr int PLANE_IMG = PH * RS;                   // halo row slots per image: 432 / 160
     static constexpr int A_ROWS = NI * PLANE_IMG;               // 432 / 640
-    static constexpr int A_CPW = (A_ROWS + 127) / 128, B_CPW = 2;   // 1 KB DMA pieces per wave: halo slab (16 row slots each) / weight sub-stage (16)
+    static constexpr int A_CPW = (A_ROWS + 127) / 128, B_CPW = 2 * BN * 64 / 1024 / NWAVES;   // 1 KB DMA pieces per wave: halo slab (16 row slots each) / weight sub-stage (16 | 32 pieces)
     static constexpr int A_BYTES = A_CPW * 8 * 1024;            // 32 KB / 40 KB
     static constexpr int B_SUB = 2 * BN * 64;                   // 16 KB
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int EPI_NJ = TILE == 16 ? WN : 2;          // 16 x 16 tiles: one-pass epilogue (whole 128-byte rows per wave), 136 KB
+    static constexpr int EPI_NJ = TILE == 16 ? 4 : 2;           // 16 x 16 tiles: 64 columns per pass (whole 128-byte rows per wave), 136 KB
+    static_assert(WN == 4 || (WN == 8 && TILE == 16), "256-column tiles: 16 x 16 maps");
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * EPI_NJ + 4) * 4;
     static constexpr int LDS_BYTES = (B_OFF + 3 * B_SUB > EPI_BYTES) ? B_OFF + 3 * B_SUB : EPI_BYTES;
     static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int TILE, int NI_>
+template <int TILE, int NI_, int WN_ = 4>
 __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
-    using C = ConvUp4Cfg<TILE, NI_>;
+    using C = ConvUp4Cfg<TILE, NI_, WN_>;
     constexpr int NI = C::NI;
     using T = __bf16;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
@@ -126,9 +129,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
         for (int dxl = 0; dxl < 2; ++dxl) a_addr[i][dxl] = lds_off(im * C::PLANE_IMG + (ly + py) * RS + lx + px + dxl, ku);
     }
-    int b_addr[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) b_addr[j] = C::B_OFF + lds_off((wave_n * WN + j) * 16 + (lane & 15), ku);
+    const int b_addr0 = C::B_OFF + lds_off(wave_n * WN * 16 + (lane & 15), ku);      // weight rows 16 apart are 1 KB apart
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -146,13 +147,16 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
             for (int dyl = 0; dyl < 2; ++dyl) {
                 if (dyl == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // see conv_dma_kernel.h
-                uint4 bfr[WN];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
+                for (int h = 0; h < WN / 4; ++h) {
+                    uint4 bfr[4];
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                    for (int j = 0; j < 4; ++j) bfr[j] = *(const uint4*)(pb + b_addr0 + (h * 4 + j) * 1024 + dyl * (BN * 64));
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], ah[i + dyl], bfr[j]);
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16t<T>(acc[i][h * 4 + j], ah[i + dyl], bfr[j]);
+                }
             }
         } else {
 #pragma unroll
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(pa + a_addr[i % NAI][dxl] + dyl * (RS * 64));
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr[j] + dyl * (BN * 64));
+                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(pb + b_addr0 + j * 1024 + dyl * (BN * 64));
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll

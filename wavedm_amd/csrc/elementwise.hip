@@ -332,46 +332,54 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1,
-                                                         int C, int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                         float premul, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd) {
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int gw = C / 32, C1 = C - C0;
-    const int lane = threadIdx.x;
-    const int cg0 = g * gw;
-    // ONE memory round trip: the group's pivot (first channel, slab 0), the first batch of partials and this lane's gamma / beta are all requested before
-    // anything is used (the kernel is one wave per (group, image): its time is dependent-load latency -- three round trips in a row before).  The
-    // accumulation order per lane (ascending item index) and the shuffle tree are unchanged, so the result is bit-identical.
-    const float4* kp = (cg0 < C0) ? &st0[((long long)b * nslab0) * C0 + cg0] : &st1[((long long)b * nslab1) * C1 + (cg0 - C0)];
-    const float kgf = kp->x;
-    double S1 = 0.0, S2 = 0.0;
-    // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
-    const int n0c = max(0, min(C0 - cg0, gw));        // channels of this group that live in tensor 0
-    const int items0 = n0c * nslab0, items = items0 + (gw - n0c) * nslab1;
-    auto load_item = [&](int it) __attribute__((always_inline)) -> float4 {
-        if (it < items0) { const int ci = it / nslab0, sl = it % nslab0; return st0[((long long)b * nslab0 + sl) * C0 + cg0 + ci]; }
-        const int j = it - items0; const int ci = n0c + j / nslab1, sl = j % nslab1;
-        return st1[((long long)b * nslab1 + sl) * C1 + (cg0 + ci - C0)];
+// mean / rstd of group g of image b from the partial statistics of [x0 | x1]: the work of ONE wave (all 64 lanes take part; every lane returns the result),
+// in two steps so that a wave that owns several groups can have all their loads in flight at once.  Shared by gn_finalize_kernel and
+// gn_finalize_apply_kernel so that both produce the same bits: the accumulation order per lane (ascending item index) and the shuffle tree are fixed.
+struct GnGroupLoad { float kgf; float4 v0[4]; int items, items0, n0c, cg0; };
+__device__ __forceinline__ float4 gn_load_item(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C1, int b,
+                                               const GnGroupLoad& L, int it) {
+    // slab counts are powers of two for every map of the model: shifts instead of ~35-instruction run-time divisions (four per item -- they were most of
+    // this kernel's instruction count)
+    auto divmod = [](int x, int d, int& q, int& r) __attribute__((always_inline)) {
+        if ((d & (d - 1)) == 0) { const int sh = __builtin_ctz(d); q = x >> sh; r = x & (d - 1); } else { q = x / d; r = x - q * d; }
     };
-    float4 v0[4];
+    int ci, sl;
+    if (it < L.items0) { divmod(it, nslab0, ci, sl); return st0[((long long)b * nslab0 + sl) * C0 + L.cg0 + ci]; }
+    divmod(it - L.items0, nslab1, ci, sl);
+    return st1[((long long)b * nslab1 + sl) * C1 + (L.cg0 + L.n0c + ci - C0)];
+}
+__device__ __forceinline__ void gn_group_load(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int g, int b, int lane,
+                                              GnGroupLoad& L) {
+    const int gw = C / 32, C1 = C - C0;
+    L.cg0 = g * gw;
+    // ONE memory round trip: the group's pivot (first channel, slab 0) and the first batch of partials are requested before anything is used
+    const float4* kp = (L.cg0 < C0) ? &st0[((long long)b * nslab0) * C0 + L.cg0] : &st1[((long long)b * nslab1) * C1 + (L.cg0 - C0)];
+    L.kgf = kp->x;
+    // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
+    L.n0c = max(0, min(C0 - L.cg0, gw));        // channels of this group that live in tensor 0
+    L.items0 = L.n0c * nslab0;
+    L.items = L.items0 + (gw - L.n0c) * nslab1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (lane + 64 * u < items) v0[u] = load_item(lane + 64 * u);
-    float gam0 = 0.f, bet0 = 0.f;
-    if (lane < gw) { gam0 = gamma[cg0 + lane]; bet0 = beta[cg0 + lane]; }
-    const double kg = (double)kgf;
+    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) L.v0[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, lane + 64 * u);
+}
+__device__ __forceinline__ void gn_group_reduce(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
+                                                int b, int lane, const GnGroupLoad& L, float& mean, float& rstd) {
+    const int gw = C / 32, C1 = C - C0;
+    double S1 = 0.0, S2 = 0.0;
+    const double kg = (double)L.kgf;
     auto accumulate = [&](const float4& v) __attribute__((always_inline)) {
         const double n = (double)v.w, d = (double)v.x - kg, a1 = (double)v.y, a2 = (double)v.z;
         S1 += a1 + n * d;
         S2 += a2 + 2.0 * d * a1 + n * d * d;
     };
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (lane + 64 * u < items) accumulate(v0[u]);
-    for (int it0 = lane + 256; it0 < items; it0 += 256) {
+    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) accumulate(L.v0[u]);
+    for (int it0 = lane + 256; it0 < L.items; it0 += 256) {
         float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < items) v[u] = load_item(it0 + 64 * u);
+        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) v[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, it0 + 64 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < items) accumulate(v[u]);
+        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) accumulate(v[u]);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -382,8 +390,27 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     const double m = S1 / N;
     double var = S2 / N - m * m;
     if (var < 0.0) var = 0.0;
-    const float mean = (float)(kg + m);
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean = (float)(kg + m);
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+__device__ __forceinline__ void gn_group_stats(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
+                                               int g, int b, int lane, float& mean, float& rstd) {
+    GnGroupLoad L;
+    gn_group_load(st0, nslab0, C0, st1, nslab1, C, g, b, lane, L);
+    gn_group_reduce(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L, mean, rstd);
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1,
+                                                         int C, int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float premul, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int gw = C / 32;
+    const int lane = threadIdx.x;
+    const int cg0 = g * gw;
+    float gam0 = 0.f, bet0 = 0.f;
+    if (lane < gw) { gam0 = gamma[cg0 + lane]; bet0 = beta[cg0 + lane]; }
+    float mean, rstd;
+    gn_group_stats(st0, nslab0, C0, st1, nslab1, C, HW, eps, g, b, lane, mean, rstd);
     if (mean_rstd != nullptr && lane == 0) { mean_rstd[((long long)b * 32 + g) * 2] = mean; mean_rstd[((long long)b * 32 + g) * 2 + 1] = rstd; }
     for (int ci = lane; ci < gw; ci += 64) {
         const int c = cg0 + ci;
@@ -392,6 +419,78 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
         scale[(long long)b * C + c] = sc * premul;
         shift[(long long)b * C + c] = (bt - mean * sc) * premul;
     }
+}
+
+// GroupNorm finalize + apply (+ SiLU, + channel concat) in ONE launch, for the consumers that normalise in a pass of their own (the 8 x 8 ResnetBlocks, the
+// AttnBlocks): workgroup (part, image) re-derives the image's 32 groups -- wave w takes groups 4 w ... 4 w + 3 with gn_group_stats, i.e. the bits of
+// gn_finalize_kernel, their loads independent of each other --, leaves scale / shift of all channels in LDS and applies them to its share of the image's
+// pixels with the arithmetic of gn_apply_kernel.  A handful of workgroups per image (not one per tile of the output): the partial statistics an image's
+// workgroups re-read stay a few hundred KB per launch.  Replaces 2-3 launches of ~5.5 us each on a strictly serial chain -- but measured (round 3,
+// rocprofv3): 12.8 us per launch against 5.7 + 5.9 for finalize + apply; compiled without the reduction 8.8, without the apply 5.8, with neither 4.8:
+// the pass is bound by moving the tensor (4 us) and by the launch itself, the reduction is ~1 us of it; -1 % end to end.  Off by default (WDM_GN_FUSED=1).
+template <typename T>
+__global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C,
+                                                                 int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 const T* __restrict__ x0, int xs0, const T* __restrict__ x1, int xs1, T* __restrict__ y, int silu,
+                                                                 int parts) {
+    constexpr int VEC = TI<T>::VEC;
+    extern __shared__ float gn_tab[];                 // scale[C] | shift[C]
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves, two groups each: both groups' partials (and gamma / beta) in flight together
+    const int gw = C / 32;
+    // the thread's first vectors of x are requested BEFORE the statistics: they do not depend on them, and the kernel's time is its chain of memory
+    // round trips (statistics -> reduction -> x -> store, each 1-2 us) -- with x in flight under the reduction one round trip is gone
+    const int pp = (HW + parts - 1) / parts;
+    const int p0 = part * pp, p1 = min(HW, p0 + pp);
+    const int cols = C / VEC, cols0 = C0 / VEC;
+    const long long nv = (long long)(p1 - p0) * cols;
+    auto x_load = [&](long long id) __attribute__((always_inline)) -> uint4 {
+        const int col = (int)(id % cols);
+        const long long bp = (long long)b * HW + p0 + id / cols;
+        const int c = col * VEC;
+        return col < cols0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+    };
+    constexpr int NPF = 4;
+    uint4 xr[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) xr[k] = x_load(id); }
+    GnGroupLoad L[2];
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        gn_group_load(st0, nslab0, C0, st1, nslab1, C, wave * 2 + k, b, lane, L[k]);
+        if (lane < gw) { gam[k] = gamma[(wave * 2 + k) * gw + lane]; bet[k] = beta[(wave * 2 + k) * gw + lane]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int g = wave * 2 + k;
+        float mean, rstd;
+        gn_group_reduce(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L[k], mean, rstd);
+        for (int ci = lane; ci < gw; ci += 64) {
+            const int c = g * gw + ci;
+            const float sc = rstd * (ci < 64 ? gam[k] : gamma[c]);
+            gn_tab[c] = sc;
+            gn_tab[C + c] = (ci < 64 ? bet[k] : beta[c]) - mean * sc;
+        }
+    }
+    __syncthreads();
+    auto apply = [&](long long id, const uint4& u) __attribute__((always_inline)) {
+        const int col = (int)(id % cols);
+        const long long bp = (long long)b * HW + p0 + id / cols;
+        const int c = col * VEC;
+        float f[VEC];
+        TI<T>::unpack(u, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = f[e] * gn_tab[c + e] + gn_tab[C + c + e];
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
+        }
+        *(uint4*)(y + bp * C + c) = TI<T>::pack(f);
+    };
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) apply(id, xr[k]); }
+    for (long long id = threadIdx.x + (long long)NPF * blockDim.x; id < nv; id += blockDim.x) apply(id, x_load(id));
 }
 
 int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s) {
@@ -414,6 +513,27 @@ int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const flo
     const float premul = for_silu_conv ? -1.4426950408889634f : 1.0f;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW,
                        nw.g, nw.b, eps, premul, scale, shift, mean_rstd);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
+// y (dense, C0 + C1 channels per pixel) = act(GroupNorm([x0 | x1])) from the tensors' partial statistics, one launch (gn_finalize_apply_kernel)
+int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0, int nslab0, const float* st1, int nslab1, const NormW& nw, float eps, int silu, void* y,
+                        int dtype, hipStream_t s) {
+    const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1, HW = x0.H * x0.W;
+    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    if (C != nw.c || C % 32 || C0 % vec || C1 % vec || C > 4096) WDM_FAIL(WDM_EINVAL, "groupnorm: %d + %d channels vs %d weights unsupported by the fused pass", C0, C1, nw.c);
+    int parts = 256 / (B > 0 ? B : 1);          // about one workgroup per CU: every workgroup repeats the image's reduction
+    if (parts < 1) parts = 1;
+    if (parts > HW / 16) parts = HW / 16 > 0 ? HW / 16 : 1;
+    const dim3 grid(parts, B);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    if (dtype == WDM_BF16)
+        hipLaunchKernelGGL(gn_finalize_apply_kernel<__bf16>, grid, dim3(1024), lds, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
+                           nw.b, eps, (const __bf16*)x0.p, x0.xs, (const __bf16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (__bf16*)y, silu, parts);
+    else
+        hipLaunchKernelGGL(gn_finalize_apply_kernel<float>, grid, dim3(1024), lds, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
+                           nw.b, eps, (const float*)x0.p, x0.xs, (const float*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (float*)y, silu, parts);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
