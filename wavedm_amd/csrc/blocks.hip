@@ -88,7 +88,7 @@ void env_cfg_refresh() {
     c.wsm = flag("WDM_WSM", 1); c.dma32 = num("WDM_DMA32", 0); c.dma_pf = num("WDM_DMA_PF", 0) == 1; c.attn_fused = flag("WDM_ATTN_FUSED", 1);
     c.attn_vt = flag("WDM_ATTN_VT", 1); c.fuse_nin = flag("WDM_FUSE_NIN", 1); c.gn_pass_hw = num("WDM_GN_PASS_HW", 64); c.grid_gn = num("WDM_GRID_GN", 1);
     c.conv_dma = num("WDM_CONV_DMA", 1) != 0; c.gemm = flag("WDM_GEMM", 1); c.bn128 = flag("WDM_CONV_BN128", 1); c.wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c.gn_fused = flag("WDM_GN_FUSED", 0); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
+    c.gn_fused = flag("WDM_GN_FUSED", 1); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
     c.bn256 = num("WDM_BN256", 1); c.bn256_half = flag("WDM_BN256_HALF", 0);
     g_env = c;
 }
@@ -214,7 +214,7 @@ static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tm
 // act(gn([x0|x1])) as one dense tensor (silu != 0: with SiLU) -- one launch (k_gn_finalize_apply), or finalize + apply per tensor with WDM_GN_FUSED=0
 static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int silu, Tens* out) {
     const int C = x0.C + (x1 ? x1->C : 0);
-    if (env_cfg().gn_fused && C <= 4096) {
+    if (env_cfg().gn_fused && gn_fused_pass_eligible(x0.C, x1 ? x1->C : 0, c.dtype)) {
         float *st0 = nullptr, *st1 = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
         int ns0 = 0, ns1 = 1;
         WDM_TRY(gn_partials_of(c, x0, &st0, &ns0, &tmp0));

@@ -127,6 +127,7 @@ int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipSt
 int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const float* st1, int nslab1, int C1, const NormW& nw,
                   float eps, int for_silu_conv, float* scale, float* shift, hipStream_t s, float* mean_rstd = nullptr);   // mean_rstd: [B][32][2], optional
 // finalize + apply (+ SiLU, + concat) in one launch: y dense [B][HW][C0 + C1]; st0 / st1 = the tensors' partial statistics
+bool gn_fused_pass_eligible(int C0, int C1, int dtype);
 int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0, int nslab0, const float* st1, int nslab1, const NormW& nw, float eps, int silu, void* y,
                         int dtype, hipStream_t s);
 // y[b][p][y_choff + c] = act(x*scale + shift); scale/shift rows are sc_ld long (channel concat: pass scale + C0), silu != 0 applies SiLU
@@ -190,7 +191,7 @@ struct EnvCfg {
     int bn256_half = 0;   // WDM_BN256_HALF=1: 128 x 256 tiles where 256 x 256 ones are too few (stand-alone +4-8 %, inside the model -10 %: cold weights, one sub-stage of lead)
     int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
-    int gn_fused = 0;     // WDM_GN_FUSED=1: GroupNorm finalize + apply (+ concat) of the pass consumers as one launch (same bits; measured 1 % slower)
+    int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
 };
 const EnvCfg& env_cfg();

@@ -421,72 +421,62 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     }
 }
 
-// GroupNorm finalize + apply (+ SiLU, + channel concat) in ONE launch, for the consumers that normalise in a pass of their own (the 8 x 8 ResnetBlocks, the
-// AttnBlocks): workgroup (part, image) re-derives the image's 32 groups -- wave w takes groups 4 w ... 4 w + 3 with gn_group_stats, i.e. the bits of
-// gn_finalize_kernel, their loads independent of each other --, leaves scale / shift of all channels in LDS and applies them to its share of the image's
-// pixels with the arithmetic of gn_apply_kernel.  A handful of workgroups per image (not one per tile of the output): the partial statistics an image's
-// workgroups re-read stay a few hundred KB per launch.  Replaces 2-3 launches of ~5.5 us each on a strictly serial chain -- but measured (round 3,
-// rocprofv3): 12.8 us per launch against 5.7 + 5.9 for finalize + apply; compiled without the reduction 8.8, without the apply 5.8, with neither 4.8:
-// the pass is bound by moving the tensor (4 us) and by the launch itself, the reduction is ~1 us of it; -1 % end to end.  Off by default (WDM_GN_FUSED=1).
+// GroupNorm finalize + apply (+ SiLU, + channel concat) in ONE launch, for the consumers that normalise in a pass of their own (the 8 x 8 ResnetBlocks,
+// the AttnBlocks).  Workgroup (q, image) owns FOUR consecutive groups: wave k finalises group 4 q + k with gn_group_stats (the bits of
+// gn_finalize_kernel; the four reductions run side by side) and all 256 threads then apply scale / shift to the groups' channels of every pixel of
+// the image with the arithmetic of gn_apply_kernel -- no statistics are reduced twice, and the channel runs of four groups (>= 128 bytes) keep the
+// accesses on whole cache lines.  The thread's first vectors of x are requested BEFORE the statistics (they do not depend on them).
+// History: a first form with a few fat workgroups per image, each repeating the image's whole reduction (16 waves x 2 groups), took 12.8 us against
+// 5.7 + 5.9 us for finalize + apply (-1 % end to end); this form has no redundant work.
 template <typename T>
-__global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C,
-                                                                 int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                                 const T* __restrict__ x0, int xs0, const T* __restrict__ x1, int xs1, T* __restrict__ y, int silu,
-                                                                 int parts) {
+__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C,
+                                                                int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                const T* __restrict__ x0, int xs0, const T* __restrict__ x1, int xs1, T* __restrict__ y, int silu) {
     constexpr int VEC = TI<T>::VEC;
-    extern __shared__ float gn_tab[];                 // scale[C] | shift[C]
-    const int part = blockIdx.x, b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves, two groups each: both groups' partials (and gamma / beta) in flight together
+    constexpr int GPW = 4;                            // groups per workgroup = waves per workgroup
+    __shared__ float tab[2][GPW * 64];                // scale | shift of the workgroup's channels (group widths up to 64)
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = C / 32;
-    // the thread's first vectors of x are requested BEFORE the statistics: they do not depend on them, and the kernel's time is its chain of memory
-    // round trips (statistics -> reduction -> x -> store, each 1-2 us) -- with x in flight under the reduction one round trip is gone
-    const int pp = (HW + parts - 1) / parts;
-    const int p0 = part * pp, p1 = min(HW, p0 + pp);
-    const int cols = C / VEC, cols0 = C0 / VEC;
-    const long long nv = (long long)(p1 - p0) * cols;
+    const int cw = GPW * gw, c_first = q * cw;        // the workgroup's channel range [c_first, c_first + cw)
+    const int cols = cw / VEC;                        // 16-byte vectors per pixel in that range (C0, gw * GPW multiples of VEC: host check)
+    const long long nv = (long long)HW * cols;
     auto x_load = [&](long long id) __attribute__((always_inline)) -> uint4 {
         const int col = (int)(id % cols);
-        const long long bp = (long long)b * HW + p0 + id / cols;
-        const int c = col * VEC;
-        return col < cols0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+        const long long bp = (long long)b * HW + id / cols;
+        const int c = c_first + col * VEC;
+        return c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
     };
     constexpr int NPF = 4;
     uint4 xr[NPF];
 #pragma unroll
     for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) xr[k] = x_load(id); }
-    GnGroupLoad L[2];
-    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        gn_group_load(st0, nslab0, C0, st1, nslab1, C, wave * 2 + k, b, lane, L[k]);
-        if (lane < gw) { gam[k] = gamma[(wave * 2 + k) * gw + lane]; bet[k] = beta[(wave * 2 + k) * gw + lane]; }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int g = wave * 2 + k;
+    {
+        const int g = q * GPW + wave;
+        float gam = 0.f, bet = 0.f;
+        if (lane < gw) { gam = gamma[g * gw + lane]; bet = beta[g * gw + lane]; }
         float mean, rstd;
-        gn_group_reduce(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L[k], mean, rstd);
-        for (int ci = lane; ci < gw; ci += 64) {
-            const int c = g * gw + ci;
-            const float sc = rstd * (ci < 64 ? gam[k] : gamma[c]);
-            gn_tab[c] = sc;
-            gn_tab[C + c] = (ci < 64 ? bet[k] : beta[c]) - mean * sc;
+        gn_group_stats(st0, nslab0, C0, st1, nslab1, C, HW, eps, g, b, lane, mean, rstd);
+        if (lane < gw) {
+            const float sc = rstd * gam;
+            tab[0][wave * gw + lane] = sc;
+            tab[1][wave * gw + lane] = bet - mean * sc;
         }
     }
     __syncthreads();
     auto apply = [&](long long id, const uint4& u) __attribute__((always_inline)) {
         const int col = (int)(id % cols);
-        const long long bp = (long long)b * HW + p0 + id / cols;
-        const int c = col * VEC;
+        const long long bp = (long long)b * HW + id / cols;
+        const int cl = col * VEC;
         float f[VEC];
         TI<T>::unpack(u, f);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) f[e] = f[e] * gn_tab[c + e] + gn_tab[C + c + e];
+        for (int e = 0; e < VEC; ++e) f[e] = f[e] * tab[0][cl + e] + tab[1][cl + e];
         if (silu) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
         }
-        *(uint4*)(y + bp * C + c) = TI<T>::pack(f);
+        *(uint4*)(y + bp * C + c_first + cl) = TI<T>::pack(f);
     };
 #pragma unroll
     for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) apply(id, xr[k]); }
@@ -518,22 +508,23 @@ int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const flo
 }
 
 // y (dense, C0 + C1 channels per pixel) = act(GroupNorm([x0 | x1])) from the tensors' partial statistics, one launch (gn_finalize_apply_kernel)
+bool gn_fused_pass_eligible(int C0, int C1, int dtype) {
+    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const int C = C0 + C1, gw = C / 32;
+    // a 16-byte vector must not straddle the seam of the concat, and the four groups of a workgroup must be whole vectors
+    return C % 32 == 0 && gw <= 64 && C0 % vec == 0 && C1 % vec == 0 && (4 * gw) % vec == 0;
+}
 int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0, int nslab0, const float* st1, int nslab1, const NormW& nw, float eps, int silu, void* y,
                         int dtype, hipStream_t s) {
     const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1, HW = x0.H * x0.W;
-    const int vec = dtype == WDM_BF16 ? 8 : 4;
-    if (C != nw.c || C % 32 || C0 % vec || C1 % vec || C > 4096) WDM_FAIL(WDM_EINVAL, "groupnorm: %d + %d channels vs %d weights unsupported by the fused pass", C0, C1, nw.c);
-    int parts = 256 / (B > 0 ? B : 1);          // about one workgroup per CU: every workgroup repeats the image's reduction
-    if (parts < 1) parts = 1;
-    if (parts > HW / 16) parts = HW / 16 > 0 ? HW / 16 : 1;
-    const dim3 grid(parts, B);
-    const size_t lds = (size_t)2 * C * sizeof(float);
+    if (C != nw.c || !gn_fused_pass_eligible(C0, C1, dtype)) WDM_FAIL(WDM_EINVAL, "groupnorm: %d + %d channels vs %d weights unsupported by the fused pass", C0, C1, nw.c);
+    const dim3 grid(8, B);
     if (dtype == WDM_BF16)
-        hipLaunchKernelGGL(gn_finalize_apply_kernel<__bf16>, grid, dim3(1024), lds, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
-                           nw.b, eps, (const __bf16*)x0.p, x0.xs, (const __bf16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (__bf16*)y, silu, parts);
+        hipLaunchKernelGGL(gn_finalize_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
+                           nw.b, eps, (const __bf16*)x0.p, x0.xs, (const __bf16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (__bf16*)y, silu);
     else
-        hipLaunchKernelGGL(gn_finalize_apply_kernel<float>, grid, dim3(1024), lds, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
-                           nw.b, eps, (const float*)x0.p, x0.xs, (const float*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (float*)y, silu, parts);
+        hipLaunchKernelGGL(gn_finalize_apply_kernel<float>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
+                           nw.b, eps, (const float*)x0.p, x0.xs, (const float*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (float*)y, silu);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
