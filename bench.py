@@ -222,7 +222,7 @@ def main():
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
         traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", f"{tag}_traffic.json")))
                 traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
@@ -337,11 +337,14 @@ def main():
         d2.model.load_state_dict(P.procedural_state_dict(cfg2, seed=61), strict=True)
         r2, x2 = P.synthetic_batch(256, patch_px=512, seed=62)
         r2, x2 = r2.to(dev), x2.to(dev)
-        t2 = timed(lambda: d2.restore_batch(r2, x2), n_warm=0)            # one pass is 8 s: the C1 passes above already warmed the clocks
+        a2.sampling_timesteps = 10
+        d2.restore_batch(r2, x2)                                            # warm-up: 10 steps of the same shapes (first-use costs, clocks)
+        a2.sampling_timesteps = 100
+        t2 = timed(lambda: d2.restore_batch(r2, x2), n_warm=0)
         a2.sampling_timesteps = 5
         fl2 = conv_flops_per_pass(lambda: d2.restore_batch(r2, x2)) * 20
         extras.append({"workload": "BASELINE.json configs[2]: 256 patches of 128x128 (512x512 px crops), 100 DDIM steps", "value": round(256 / t2, 3),
-                       "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 1, "warmup": 0, "conv_tflops": round(fl2 / t2 / 1e12, 1)})
+                       "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 1, "warmup": "10 DDIM steps of the same batch", "conv_tflops": round(fl2 / t2 / 1e12, 1)})
         log(f"[bench] extra configs[2]: {256 / t2:.2f} img/s ({t2:.2f} s per 256 patches)")
         del d2, r2, x2
         torch.cuda.empty_cache()
@@ -353,6 +356,7 @@ def main():
         rp, xp = rp.to(dev), xp.to(dev)
         a.sampling_timesteps = 10
         modes = {}
+        headline_rel = None
         for name in ("f32x3", "f32"):
             df = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=name)
             df.model.load_state_dict(sd, strict=True)
@@ -365,12 +369,23 @@ def main():
                 m["rel_linf_vs_oracle"] = float(f"{max(rel(xl.cpu(), cpu_sample['xs_last']), rel(x0g.cpu(), cpu_sample['x0_m5'])):.3e}")
                 if cpu:
                     m["speedup_vs_cpu"] = round(ips / cpu["value"], 1)
+            if name == "f32" and xs_last is not None:
+                # the HEADLINE run's own outputs, full length: the first four of its 64 crops again in exact fp32 (an image's result does not depend
+                # on the batch it sits in), compared with what the timed bf16 passes produced for them
+                a.sampling_timesteps = args.ddim_steps
+                _, xl32, x032 = df.restore_batch(rainy[:4].contiguous(), x_T[:4].contiguous())
+                a.sampling_timesteps = 10
+                headline_rel = max(rel(xs_last[:4].cpu(), xl32.cpu()), rel(x0[:4].cpu(), x032.cpu()))
             modes[name] = m
             log(f"[bench] parity mode {name}: {ips:.2f} img/s {m}")
             del df
             torch.cuda.empty_cache()
         parity_mode = modes["f32x3"]
         parity_mode["exact_f32"] = modes["f32"]
+        if headline_rel is not None:
+            parity_mode["rel_linf_bf16_vs_f32_headline"] = float(f"{headline_rel:.3e}")
+            parity_mode["headline_checked_on"] = (f"crops 0-3 of the timed batch, all {args.ddim_steps} DDIM steps: xs[-1] and x0_preds[-5] of the timed bf16 passes "
+                                                  "against the exact-f32 HIP path (itself <= 2e-6 from the CPU oracle over 100 steps: tests/test_gpu_unet.py)")
         if cpu_sample is not None:
             _, xl, x0g = d.restore_batch(cpu_sample["rainy"].to(dev), cpu_sample["x_T"].to(dev))
             parity_mode["rel_linf_bf16_vs_oracle"] = float(f"{max(rel(xl.cpu(), cpu_sample['xs_last']), rel(x0g.cpu(), cpu_sample['x0_m5'])):.3e}")

@@ -193,7 +193,12 @@ class DenoisingDiffusion_Wavelet(object):
         skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
         seq = range(0, self.config.diffusion.num_diffusion_timesteps, skip)
         if patch_locs is None:
-            raise NotImplementedError("sample_image without patch_locs is the pixel-domain path (utils/sampling.py:23)")
+            # ddm_wavelet.py:305-306 falls through to utils.sampling.generalized_steps (utils/sampling.py:23-44): every image is ONE patch of the
+            # model's resolution and the UNet sees [x_cond | x_t] (its conv_in must be built for that width: model.use_other_channels False)
+            if not self.config.data.begin_from_noise:
+                pass                                                            # generalized_steps starts from x as given (no q-sample of x_cond)
+            xs = sampling.ddim_sample(self.model, x, x_cond, None, list(seq), self.betas, corners=None, max_batch=getattr(self.args, "max_batch", 64))
+            return xs[0][-1] if last else xs
         xs = self.generalized_steps_overlapping(x, x_cond, seq, self.model, self.betas, eta=0., corners=patch_locs,
                                                 p_size=patch_size, total=total, use_global=use_global,
                                                 x_other=x_other, use_other=use_other)
