@@ -34,9 +34,14 @@ def short(name: str) -> str:
     m = re.search(r"conv_dmap_kernelILb(\d)E", name)
     if m:
         return "convdmap_3x3s1_t16x16x1_bn128w8_bf16" + ("_2pass" if m.group(1) == "1" else "")
-    m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E", name)
+    m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
     if m:
-        return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn128w8_bf16"
+        return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn{32 * int(m.group(3) or 4)}w8_bf16"
+    m = re.search(r"conv_dma8_kernelILi(\d+)E", name)
+    if m:
+        return f"convdma8_3x3s1_t8x8x2_bn{m.group(1)}w4_bf16"
+    if "attn_fused_kernel" in name:
+        return "attn_fused_n256_bf16"
     m = re.search(r"conv_gemm_kernelI((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
