@@ -150,6 +150,15 @@ size_t wdm_unet_workspace_bytes(const wdm_unet* u, int B);
  * eps_out: (B, out_ch, R, R) NCHW f32 */
 int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int B, float* eps_out,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The timestep-dependent part of the network -- sinusoidal embedding, temb MLP and every ResnetBlock's temb_proj (models/unet.py:10-28, 225-230,
+ * 354-357, 125) -- depends on t alone.  A sampler knows its whole timestep sequence up front (models/ddm_wavelet.py:296-297): wdm_unet_temb_table
+ * computes the rows for all n timesteps in four launches, temb_out[n][wdm_unet_temb_rows(u)] (f32, device), and wdm_unet_forward_temb runs one UNet
+ * call from one row of it (shared by the B images) -- the same bits as wdm_unet_forward with that timestep, four launches fewer per call.
+ * The table is a function of the weights: rebuild it after a weight update.  workspace: the forward workspace serves. */
+int wdm_unet_temb_rows(const wdm_unet* u);
+int wdm_unet_temb_table(wdm_unet* u, const float* t, int n, float* temb_out, void* workspace, size_t workspace_bytes, void* stream);
+int wdm_unet_forward_temb(wdm_unet* u, const void* x96, const float* temb_row, int B, float* eps_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- per-block entry points (unit parity tests; same code the UNet executor runs) -----------
  * Weights are given in the reference layout as fp32 device pointers and packed on the fly into

@@ -324,3 +324,28 @@ def test_checkpoint_formats(tmp_path):
     torch.save({"epoch": 0, "step": 0, "state_dict": bad}, path)
     with pytest.raises(RuntimeError):
         d.load_ddm_ckpt(path)                                                        # strict=True like the reference
+
+
+def test_temb_table_gives_the_bits_of_per_step_embedding():
+    """wdm_unet_temb_table + wdm_unet_forward_temb (the sampler's default: the timestep-dependent rows of a whole DDIM sequence in four launches) against
+    wdm_unet_forward with the timestep itself: same rows, same UNet output, same 6-step trajectory (WAVEDM_TEMB_TABLE=0 switches the sampler back)."""
+    import os
+    from wavedm_amd import procedural as P
+    net = build(P.raindrop_wavelet_config(), "bf16")
+    x = seeded((3, 64, 64, 96), 5).cuda().to(torch.bfloat16).contiguous()
+    ts = torch.tensor([990.0, 500.0, 10.0], device="cuda")
+    tab = net.temb_table(ts, B=3)
+    for k in range(3):
+        a = net.forward_nhwc(x, ts[k:k + 1], torch.empty(3, 3, 64, 64, device="cuda"))
+        b = net.forward_nhwc(x, None, torch.empty(3, 3, 64, 64, device="cuda"), temb_row=tab[k])
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    d, _ = make_diffusion(P.reduced_config(), "f32", 6)
+    rainy, x_T = P.synthetic_batch(2, patch_px=64)
+    got = d.restore_batch(rainy.cuda(), x_T.cuda())
+    os.environ["WAVEDM_TEMB_TABLE"] = "0"
+    try:
+        want = d.restore_batch(rainy.cuda(), x_T.cuda())
+    finally:
+        del os.environ["WAVEDM_TEMB_TABLE"]
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)

@@ -79,6 +79,9 @@ def lib():
         "wdm_unet_mark_loaded": (i, [vp]),
         "wdm_unet_workspace_bytes": (sz, [vp, i]),
         "wdm_unet_forward": (i, [vp, vp, vp, i, i, vp, vp, sz, vp]),
+        "wdm_unet_temb_rows": (i, [vp]),
+        "wdm_unet_temb_table": (i, [vp, vp, i, vp, vp, sz, vp]),
+        "wdm_unet_forward_temb": (i, [vp, vp, vp, i, vp, vp, sz, vp]),
         "wdm_resblock_forward": (i, [vp, C.POINTER(ResblockParams), vp, i, vp, i, vp, i, i, i, i, i, vp, i, vp, sz, vp]),
         "wdm_attn_forward": (i, [vp, C.POINTER(AttnParams), vp, i, i, i, vp, i, vp, sz, vp]),
         "wdm_conv_forward": (i, [vp, vp, vp, i, i, i, vp, i, i, i, vp, i, vp, sz, vp]),
@@ -129,7 +132,7 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_pack_channels", "wdm_ddim_update", "wdm_patch_accumulate", "wdm_ddim_from_sums", "wdm_nchw_to_nhwc", "wdm_nhwc_to_nchw", "wdm_unet_create",
             "wdm_unet_destroy", "wdm_unet_num_params", "wdm_unet_param_info", "wdm_unet_packed_bytes",
             "wdm_unet_set_packed", "wdm_unet_load_param", "wdm_unet_mark_loaded", "wdm_unet_workspace_bytes",
-            "wdm_unet_forward", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
+            "wdm_unet_forward", "wdm_unet_temb_rows", "wdm_unet_temb_table", "wdm_unet_forward_temb", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",

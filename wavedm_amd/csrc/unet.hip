@@ -143,7 +143,8 @@ struct wdm_unet {
     }
     AttnW aw(const AttnD& d) const { AttnW a; a.c = d.c; a.n = nw(d.n); a.qk = cw(d.qk); a.v = cw(d.v); a.proj = cw(d.proj); return a; }
 
-    int forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out);
+    int forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out, const float* temb_pre = nullptr);
+    int temb_table(Ctx& c, const float* t, int n_t, float* temb_all);
 };
 
 int wdm_unet::build() {
@@ -215,15 +216,13 @@ int wdm_unet::build() {
     return WDM_OK;
 }
 
-int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out) {
-    const int nres = cfg.n_levels, nrb = cfg.num_res_blocks, R = cfg.resolution;
-    // ---- timestep embedding MLP + every block's temb projection (depends only on t)
-    float *emb, *t0, *t1, *temb_all;
+int wdm_unet::temb_table(Ctx& c, const float* t, int n_t, float* temb_all) {
+    // timestep embedding MLP + every block's temb projection: depends only on t (unet.py:10-28, 225-230, 354-357, 125)
+    float *emb, *t0, *t1;
     auto af = [&](size_t n, float** p) -> int { *p = (float*)c.ar->alloc(n * 4); if (!*p) WDM_FAIL(WDM_ENOMEM, "workspace too small"); return WDM_OK; };
     WDM_TRY(af((size_t)n_t * cfg.ch, &emb));
     WDM_TRY(af((size_t)n_t * temb_ch, &t0));
     WDM_TRY(af((size_t)n_t * temb_ch, &t1));
-    WDM_TRY(af((size_t)n_t * temb_rows, &temb_all));
     if (!c.dry) {
         WDM_TRY(k_timestep_embedding(t, n_t, cfg.ch, emb, c.s));
         WDM_TRY(k_linear(emb, n_t, cfg.ch, (const float*)(packed + d0w), (const float*)(packed + d0b), temb_ch, t0, 2, c.s));
@@ -231,6 +230,20 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         WDM_TRY(k_linear(t1, n_t, temb_ch, (const float*)(packed + temb_w_off), (const float*)(packed + temb_b_off), temb_rows, temb_all, 1, c.s));
     }
     c.ar->free(emb); c.ar->free(t0); c.ar->free(t1);
+    return WDM_OK;
+}
+
+int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out, const float* temb_pre) {
+    const int nres = cfg.n_levels, nrb = cfg.num_res_blocks, R = cfg.resolution;
+    // ---- timestep embedding MLP + every block's temb projection (depends only on t): computed here, or taken from a table the caller made for
+    // all the timesteps of a sampling run at once (temb_pre: one row, shared by the images)
+    float* temb_all = nullptr;
+    if (temb_pre) { temb_all = const_cast<float*>(temb_pre); n_t = 1; }
+    else {
+        temb_all = (float*)c.ar->alloc((size_t)n_t * temb_rows * 4);
+        if (!temb_all) WDM_FAIL(WDM_ENOMEM, "workspace too small");
+        WDM_TRY(temb_table(c, t, n_t, temb_all));
+    }
 
     Tens x;
     x.p = (void*)x96; x.C = cfg.in_channels; x.H = R; x.W = R; x.xs = cfg.in_channels;
@@ -304,7 +317,7 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         c.ar->free(sc); c.ar->free(sh);
     }
     free_tens(c, h);
-    c.ar->free(temb_all);
+    if (!temb_pre) c.ar->free(temb_all);
     if (!hs.empty()) WDM_FAIL(WDM_ESTATE, "internal: skip stack not empty (%zu)", hs.size());
     return WDM_OK;
 }
@@ -403,6 +416,24 @@ size_t wdm_unet_workspace_bytes(const wdm_unet* u, int B) {
     if (rc != WDM_OK) return 0;
     const size_t extra = (size_t)(B - 1) * (u->cfg.ch + 2 * (size_t)u->temb_ch + u->temb_rows) * 4 + 4096;
     return ar.peak() + align_up(extra, 256);
+}
+int wdm_unet_temb_rows(const wdm_unet* u) { return u ? u->temb_rows : 0; }
+int wdm_unet_temb_table(wdm_unet* u, const float* t, int n, float* temb_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!u || !t || !temb_out || !workspace || n <= 0) WDM_FAIL(WDM_EINVAL, "wdm_unet_temb_table: null argument");
+    if (!u->all_loaded) WDM_FAIL(WDM_ESTATE, "wdm_unet_temb_table: parameters not loaded");
+    if (((uintptr_t)workspace) & 255) WDM_FAIL(WDM_EINVAL, "wdm_unet_temb_table: workspace must be 256-byte aligned");
+    Arena ar(workspace, workspace_bytes);
+    Ctx c{(hipStream_t)stream, u->cfg.dtype, 1, &ar, false};
+    return u->temb_table(c, t, n, temb_out);
+}
+int wdm_unet_forward_temb(wdm_unet* u, const void* x96, const float* temb_row, int B, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!u || !x96 || !temb_row || !eps_out || !workspace) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward_temb: null argument");
+    if (!u->all_loaded) WDM_FAIL(WDM_ESTATE, "wdm_unet_forward_temb: parameters not loaded");
+    if (B <= 0) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward_temb: B=%d", B);
+    if (((uintptr_t)workspace) & 255) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward_temb: workspace must be 256-byte aligned");
+    Arena ar(workspace, workspace_bytes);
+    Ctx c{(hipStream_t)stream, u->cfg.dtype, B, &ar, false};
+    return u->forward(c, x96, nullptr, 1, eps_out, temb_row);
 }
 int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int B, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!u || !x96 || !t || !eps_out || !workspace) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward: null argument");

@@ -8,6 +8,8 @@ reference nothing leaves the GPU inside the loop (it does `.to('cpu')` twice and
 syncs per step, ddm_wavelet.py:498-504)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -131,6 +133,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         seq_next = [-1] + seq[:-1]
         abar = alpha_bar_table(betas)
         t_dev = torch.tensor([float(v) for v in reversed(seq)], dtype=torch.float32).to(dev)
+        # the timestep-dependent part of the UNet (embedding MLP, every temb_proj) for the WHOLE sequence at once: four launches per run instead of per step
+        temb = unet.temb_table(t_dev, B=min(max(n, 1), max_batch)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
         xs, x0_preds = [x], []
         xt = x
         n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
@@ -146,7 +150,7 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             if n:
                 _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
             for i in range(0, n, max_batch):
-                unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch])
+                unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
             x0 = torch.empty_like(x)
             xn = torch.empty_like(x)
             if sharded:

@@ -214,15 +214,33 @@ class DiffusionUNet(nn.Module):
         return self._ws[key]
 
     # ---- forward -------------------------------------------------------------------------------
-    def forward_nhwc(self, x96, t, eps_out):
-        """x96: (B,R,R,Cin) NHWC in the compute dtype; t: (n,) fp32 device; eps_out: (B,out_ch,R,R) fp32."""
+    def temb_table(self, t, B=1):
+        """Rows of the timestep-dependent part of the network (embedding MLP + every temb_proj) for all timesteps t (n,) fp32 device at once:
+        (n, temb_rows) fp32.  A sampler builds it once per run and feeds forward_nhwc one row per step (include/wavedm.h: wdm_unet_temb_table)."""
+        assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 1
+        self.pack_weights()
+        L = _lib.lib()
+        with torch.cuda.device(t.device):
+            out = torch.empty(t.numel(), int(L.wdm_unet_temb_rows(self._u)), dtype=torch.float32, device=t.device)
+            ws = self.workspace(B, t.device)
+            _lib.check(L.wdm_unet_temb_table(self._u, _lib.ptr(t), int(t.numel()), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        return out
+
+    def forward_nhwc(self, x96, t, eps_out, temb_row=None):
+        """x96: (B,R,R,Cin) NHWC in the compute dtype; t: (n,) fp32 device; eps_out: (B,out_ch,R,R) fp32.
+        temb_row: one row of temb_table() for this call's timestep (then t is not read)."""
         B = x96.shape[0]
         assert x96.is_contiguous() and x96.dtype == self._torch_dtype and tuple(x96.shape[1:]) == (self.resolution, self.resolution, self.in_channels)
         assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and tuple(eps_out.shape) == (B, self.out_ch, self.resolution, self.resolution)
-        assert t.dtype == torch.float32 and t.is_cuda and t.numel() in (1, B)
         self.pack_weights()
         with torch.cuda.device(x96.device):
             ws = self.workspace(B, x96.device)
+            if temb_row is not None:
+                assert temb_row.dtype == torch.float32 and temb_row.is_cuda and temb_row.is_contiguous() and temb_row.dim() == 1
+                _lib.check(_lib.lib().wdm_unet_forward_temb(self._u, _lib.ptr(x96), _lib.ptr(temb_row), B, _lib.ptr(eps_out),
+                                                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+                return eps_out
+            assert t.dtype == torch.float32 and t.is_cuda and t.numel() in (1, B)
             _lib.check(_lib.lib().wdm_unet_forward(self._u, _lib.ptr(x96), _lib.ptr(t), int(t.numel()), B, _lib.ptr(eps_out),
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         return eps_out
