@@ -118,3 +118,24 @@ def test_fused_groupnorm_pass_gives_the_bits_of_finalize_plus_apply(gu, dtype):
         x = gu.seeded((2, C, H, H), 9)
         a = _with({"WDM_GN_FUSED": "1"}, lambda: gu.attn(asd, "at", x, dtype))
         assert torch.equal(a, _with({"WDM_GN_FUSED": "0"}, lambda: gu.attn(asd, "at", x, dtype)))
+
+
+@pytest.mark.parametrize("c,H,B", [(256, 32, 3), (512, 16, 5), (128, 32, 2)])
+def test_groupnorm_finalised_in_the_conv_prologue_agrees_with_gn_finalize(gu, c, H, B):
+    """gn_inline.h: conv2 of a ResnetBlock finalises its GroupNorm from conv1's group-level partials inside its own prologue (maps up to 32 x 32) instead of
+    a gn_finalize launch.  Same statistics summed in another association (fp32 group merge in the producer, fp64 over the slabs in the consumer):
+    agreement far inside the bf16 bound, and the f32 oracle is the yardstick for both."""
+    shapes = {"norm1.weight": (c,), "norm1.bias": (c,), "conv1.weight": (c, c, 3, 3), "conv1.bias": (c,), "temb_proj.weight": (c, 512),
+              "temb_proj.bias": (c,), "norm2.weight": (c,), "norm2.bias": (c,), "conv2.weight": (c, c, 3, 3), "conv2.bias": (c,)}
+    sd = gu.blk_sd("rb", shapes)
+    x, t = gu.seeded((B, c, H, H), 5), gu.seeded((B, 512), 6)
+    y = gu.resblock(sd, "rb", x, None, t, "bf16")                                   # default: in-prologue finalize for conv2
+    y_fin = _with({"WDM_GN_INLINE": "0"}, lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))
+    y_f32 = gu.resblock(sd, "rb", x, None, t, "f32")
+    assert not torch.equal(y, y_fin)                                                # two different paths really ran
+    # measured: 0.0004 % ... 0.06 % of the outputs differ, each by ONE bf16 ulp (a conv input that rounded the other way): <= 2^-7 of the largest output
+    assert rel_linf(y, y_fin) <= 8e-3 and float(((y - y_fin).abs() > 0).float().mean()) <= 1e-2
+    assert rel_linf(y, y_f32) <= gu.TOL["bf16"] and rel_linf(y_fin, y_f32) <= gu.TOL["bf16"]
+    assert torch.equal(y, gu.resblock(sd, "rb", x, None, t, "bf16"))                # deterministic
+    for env in ({"WDM_BN256": "0"}, {"WDM_BN256": "2"}, {"WDM_PERSIST": "2", "WDM_PERSIST_MIN": "1"}, {"WDM_PERSIST": "1", "WDM_PERSIST_MIN": "1"}, {"WDM_DMA32": "2"}):
+        assert torch.equal(y, _with(env, lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))), env      # every tiling finalises alike

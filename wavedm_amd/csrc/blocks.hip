@@ -10,6 +10,7 @@
 
 #include <mutex>
 #include "common.h"
+#include "gn_inline.h"
 
 namespace wdm {
 
@@ -67,7 +68,7 @@ int alloc_tens(Ctx& c, int C, int H, int W, Tens* t) {
 void free_tens(Ctx& c, Tens& t) {
     c.ar->free(t.p);
     if (t.stats) c.ar->free(t.stats);
-    t.p = nullptr; t.stats = nullptr; t.nslab = 0;
+    t.p = nullptr; t.stats = nullptr; t.gst = nullptr; t.nslab = 0;
 }
 
 static int alloc_f32(Ctx& c, size_t n, float** p) {
@@ -88,7 +89,7 @@ void env_cfg_refresh() {
     c.wsm = flag("WDM_WSM", 1); c.dma32 = num("WDM_DMA32", 0); c.dma_pf = num("WDM_DMA_PF", 0) == 1; c.attn_fused = flag("WDM_ATTN_FUSED", 1);
     c.attn_vt = flag("WDM_ATTN_VT", 1); c.fuse_nin = flag("WDM_FUSE_NIN", 1); c.gn_pass_hw = num("WDM_GN_PASS_HW", 64); c.grid_gn = num("WDM_GRID_GN", 1);
     c.conv_dma = num("WDM_CONV_DMA", 1) != 0; c.gemm = flag("WDM_GEMM", 1); c.bn128 = flag("WDM_CONV_BN128", 1); c.wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c.gn_fused = flag("WDM_GN_FUSED", 1); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
+    c.gn_inline = flag("WDM_GN_INLINE", 1); c.up4_gn = num("WDM_UP4_GN", 1); c.gn_fused = flag("WDM_GN_FUSED", 1); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
     c.bn256 = num("WDM_BN256", 1); c.bn256_half = flag("WDM_BN256_HALF", 0);
     g_env = c;
 }
@@ -109,7 +110,7 @@ int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
              int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats, const ConvW* shortcut,
-             const Tens* sx0, const Tens* sx1) {
+             const Tens* sx0, const Tens* sx1, const NormW* gn_inl) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -132,7 +133,11 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.w_bytes = (unsigned)((size_t)w.k * w.k * w.rows_pad * w.cin * dsize(c.dtype));
     a.w_sm = (mode == MODE_S1 && w.k == 3) ? w.w_sm : nullptr;
     a.bias = w.b; a.alpha = 1.0f;
-    a.pro = scale ? 1 : 0; a.scale = scale; a.shift = shift;
+    a.pro = (scale || gn_inl) ? 1 : 0; a.scale = scale; a.shift = shift;
+    if (gn_inl) {
+        if (x1 || !x0.gst || scale || gn_inl->c != Cin) WDM_FAIL(WDM_EINVAL, "conv: in-prologue GroupNorm needs a single input with group partials");
+        a.gin = x0.gst; a.gin_nslab = x0.nslab; a.gn_gamma = gn_inl->g; a.gn_beta = gn_inl->b; a.gn_eps = 1e-6f;
+    }
     a.temb = temb; a.temb_ld = temb_ld; a.temb_per_image = temb_per_image;
     a.res = res ? res->p : nullptr; a.res_s = res ? res->xs : 0;
     a.y = y; a.y_mode = y_mode; a.y_s = w.cout;
@@ -156,9 +161,13 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         q.query_nslab = &nslab;
         WDM_TRY(launch_conv(q, mode, c.dtype, c.s));
         out->nslab = nslab;
-        out->stats = (float*)c.ar->alloc(gn_stats_bytes(c.B, nslab, w.cout));
+        // group-level partials ride behind the per-channel ones where a consumer can finalise from them (gn_inline.h): group widths 4 / 8 / 16
+        const bool want_gst = c.dtype == WDM_BF16 && env_cfg().gn_inline && gn_inline_shape_ok(w.cout, nslab);
+        const size_t sb = gn_stats_bytes(c.B, nslab, w.cout);
+        out->stats = (float*)c.ar->alloc(sb + (want_gst ? (size_t)c.B * nslab * 96 * sizeof(float) : 0));
         if (!out->stats) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
         a.stats = out->stats; a.stats_nslab = nslab;
+        if (want_gst) { out->gst = (float*)((char*)out->stats + sb); a.gst = out->gst; }
     }
     if (c.dry) return WDM_OK;
     return launch_conv(a, mode, c.dtype, c.s);
@@ -238,6 +247,13 @@ static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x
 }
 static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, Tens* out) { return materialize_gn(c, nw, x0, x1, 1, out); }
 
+// a 3x3 conv with the GroupNorm+SiLU prologue can finalise the norm itself when it will run on an LDS-DMA 3x3 kernel (conv_dispatch.inc: bf16, 16-pixel
+// multiple maps, Cout >= 128) and its single input carries group partials (Cin = 128 / 256 / 512)
+static bool gn_inline_ok(const Ctx& c, const Tens& x0, const Tens* x1, int cout) {
+    return env_cfg().gn_inline && env_cfg().conv_dma && c.dtype == WDM_BF16 && !x1 && x0.gst != nullptr && gn_inline_shape_ok(x0.C, x0.nslab) && x0.H % 16 == 0 &&
+           x0.W % 16 == 0 && cout >= 128;
+}
+
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
@@ -250,6 +266,9 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
         WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
         free_tens(c, a1);
+    } else if (gn_inline_ok(c, x0, x1, w.cout)) {
+        // conv1's GroupNorm finalised in conv1's own prologue from the producer's group partials: no gn_finalize launch (gn_inline.h)
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n1));
     } else {
         WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
         WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
@@ -271,6 +290,9 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));
         else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
         free_tens(c, a2);
+    } else if (gn_inline_ok(c, t1, nullptr, w.cout)) {
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, &w.n2));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n2));
     } else {
         WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
         if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));

@@ -62,6 +62,7 @@ struct Tens {
     int xs = 0;   // pixel stride in elements
     float* stats = nullptr;   // GroupNorm partial statistics float4[B][nslab][C] written by the producing conv, or nullptr
     int nslab = 0;
+    float* gst = nullptr;     // group-level partials float[B][nslab][32][3] behind them in the same allocation (C = 128 / 256 / 512), or nullptr: gn_inline.h
 };
 
 struct Ctx {
@@ -192,6 +193,8 @@ struct EnvCfg {
     int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
+    int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
+    int up4_gn = 1;       // WDM_UP4_GN=2|4|8: N-tile groups per XCD of the 8 x 8 sub-pixel upsample kernel
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
 };
 const EnvCfg& env_cfg();
@@ -202,9 +205,10 @@ int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
 
 // ---- blocks (blocks.hip) ----------------------------------------------------------------------
 // want_stats: also emit the GroupNorm partial statistics of the output (out->stats) from the conv epilogue
+// gn_inl: GroupNorm(+SiLU) of the single input x0 finalised in the conv's own prologue from x0.gst (gn_inline.h); scale / shift are then null
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
-             bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr);
+             bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr);
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
 int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);

@@ -18,6 +18,7 @@
 // sub-stage (96 | 48 MFMAs per wave) of lead.  Per wave and sub-stage: 6 weight pieces (+ 3 | 2 halo pieces once per slab).
 #pragma once
 #include "conv_kernel.h"
+#include "gn_inline.h"
 
 #ifndef WDM_DABL
 #define WDM_DABL 0
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
 
     // ---- prologue: table, halo slab 0, weight columns (0, 0) and (0, 1); every step waits only for its own operands (in-order DMA queue)
     const bool pro = a.pro != 0;
-    if (pro && wave * 256 < C::MAX_CIN) {
+    const bool gn_inl = a.gin != nullptr;          // GroupNorm finalised here from the input's group partials (gn_inline.h)
+    if (pro && gn_inl) gn_inline_issue<C::MAX_CIN>(a, img0, wave, lane, lds0 + C::A_BYTES, lds0 + C::SC_OFF, dma16, make_q);
+    else if (pro && wave * 256 < C::MAX_CIN) {
         const i32x4 q_sc = make_q(a.scale + (long long)img0 * a.Cin, (unsigned)(a.Cin * 4)), q_sh = make_q(a.shift + (long long)img0 * a.Cin, (unsigned)(a.Cin * 4));
         const unsigned vo = (unsigned)((wave * 256 + lane * 4) * 4);
         dma16(q_sc, lds0 + C::SC_OFF + wave * 1024, vo, 0);
@@ -207,6 +210,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     issue_b(0, 1, 1);
     if (pro) {
         WDM_DMA_SYNC(2 * BCP);                     // every wave's table piece and this lane's halo pieces landed
+        if (gn_inl) {
+            gn_inline_table<C::MAX_CIN>((const float*)(smem + C::A_BYTES), (float*)(smem + C::SC_OFF), a.gin_nslab, a.Cin, a.Hin * a.Win, a.gn_eps, tid);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         transform(0);
     }
     WDM_DMA_SYNC(BCP);                             // weights (0, 0) in, every lane's transform visible

@@ -21,6 +21,7 @@
 // lane only, so each lane needs one scale/shift unit per slab.
 #pragma once
 #include "conv_kernel.h"
+#include "gn_inline.h"
 
 // tools/dma_ablate.hip builds this kernel with phases switched off (0 in the library): 1 no GroupNorm+SiLU transform, 2 no MFMAs (the
 // fragment reads stay), 4 no halo DMA after slab 0, 8 no weight DMA after the prologue, 16 no fragment reads either (with 2)
@@ -258,7 +259,9 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
     // the weights -- and each step waits only for its own operands: the table goes to LDS while the halo is in flight, the halo is transformed while
     // the weights are, and the K loop starts on weights (0, 0) with (0, 1), (0, 2) still under way (its counted waits allow exactly that).
     constexpr int NB0 = C::NRING == 4 ? 3 : 2;                               // weight sub-stages requested by the prologue
-    if (pro && wave * 256 < C::MAX_CIN) {
+    const bool gn_inl = a.gin != nullptr;          // GroupNorm finalised here from the input's group partials (gn_inline.h) instead of a fetched table
+    if (pro && gn_inl) gn_inline_issue<C::MAX_CIN>(a, img0, wave, lane, lds0 + C::A_BYTES, lds0 + C::SC_OFF, dma16, make_q);
+    else if (pro && wave * 256 < C::MAX_CIN) {
         // scale / shift rows of the image by DMA as well (256 floats per piece, wave w takes floats [256 w, 256 w + 256) of each; past Cin the
         // descriptor returns zeros): no compiler-visible load in the prologue, whose wait would drain the whole queue.  shift sits MAX_CIN floats
         // behind scale whatever Cin is, so the zero fill of a short row never lands on it.
@@ -276,6 +279,11 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NB0 * BCP) : "memory");      // every wave's table piece and this lane's halo pieces landed
         __builtin_amdgcn_sched_barrier(0);
         WDM_ETS(13);
+        if (gn_inl) {
+            gn_inline_table<C::MAX_CIN>((const float*)(smem + C::A_BYTES), (float*)(smem + C::SC_OFF), a.gin_nslab, a.Cin, a.Hin * a.Win, a.gn_eps, tid);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         transform(0);
     }
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NB0 - 1) * BCP) : "memory");    // weights (0, 0) in, every lane's transform visible

@@ -126,20 +126,20 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         }
     };
     // head of a tile's DMA stream: table (two pieces per wave), halo slab 0, weight sub-stages 0 and 1 (slots 2, 3)
-    auto issue_head = [&](int part) __attribute__((always_inline)) {      // part 0: everything, 1: halo only, 2: table and weights (halo already out)
-        if (part == 1) { issue_a(0); return; }
-        if (part == 2) {
-            // the table rides BEHIND nothing it needs: order [A (in the hook)] [table] [B00] [B01] keeps the counted waits of the loop top valid
-        }
-        if (pro && wave * 256 < C::MAX_CIN) {
+    // head of a tile's DMA stream: table (or the image's group partials, gn_inline.h), halo slab 0, weight sub-stages 0 and 1 (slots 2, 3).
+    // part 0: everything (first tile) | 1: halo only (one-pass hook) | 2: table / partials + weights (one-pass, behind the epilogue: the table region and
+    // A[1], the partials' scratch, lie under the epilogue tile) | 3: two-pass hook: everything but the partials | 4: the partials (two-pass, behind the epilogue)
+    auto issue_head = [&](int part) __attribute__((always_inline)) {
+        const bool inl = ap->gin != nullptr;
+        if (pro && inl && (part == 0 || part == 2 || part == 4)) gn_inline_issue<C::MAX_CIN>(*ap, img0, wave, lane, lds0 + C::A_BYTES, lds0 + C::SC_OFF, dma16, make_q);
+        if (pro && !inl && part != 1 && part != 4 && wave * 256 < C::MAX_CIN) {
             const i32x4 q_sc = make_q(ap->scale + (long long)img0 * ap->Cin, (unsigned)(ap->Cin * 4)), q_sh = make_q(ap->shift + (long long)img0 * ap->Cin, (unsigned)(ap->Cin * 4));
             const unsigned vo = (unsigned)((wave * 256 + lane * 4) * 4);
             dma16(q_sc, lds0 + C::SC_OFF + wave * 1024, vo, 0);
             dma16(q_sh, lds0 + C::SC_OFF + C::MAX_CIN * 4 + wave * 1024, vo, 0);
         }
-        if (part == 0) issue_a(0);
-        issue_b(0, 0, 2);
-        issue_b(0, 1, 3);
+        if (part == 0 || part == 1 || part == 3) issue_a(0);
+        if (part == 0 || part == 2 || part == 3) { issue_b(0, 0, 2); issue_b(0, 1, 3); }
     };
     const float* sct = (const float*)(smem + C::SC_OFF);
     auto transform = [&](int s) __attribute__((always_inline)) {
@@ -186,8 +186,15 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         WDM_PTS(0);
         issue_b(0, 2, 0);
         if (pro) {
-            WDM_DMA_SYNC(3 * BCP);                 // table and this lane's halo pieces landed (younger: the three weight sub-stages)
+            // table (or the image's group partials) and this lane's halo pieces landed: younger are the three weight sub-stages -- except in the
+            // two-pass form after the first tile, where the table / partials go out behind the epilogue, i.e. behind sub-stages 0 and 1
+            if (TWO_PASS && tile_it > 0 && ap->gin != nullptr) WDM_DMA_SYNC(BCP); else WDM_DMA_SYNC(3 * BCP);
             WDM_PTS(1);
+            if (ap->gin != nullptr) {
+                gn_inline_table<C::MAX_CIN>((const float*)(smem + C::A_BYTES), (float*)(smem + C::SC_OFF), ap->gin_nslab, ap->Cin, ap->Hin * ap->Win, ap->gn_eps, tid);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
             transform(0);
         }
         WDM_DMA_SYNC(2 * BCP);                     // weights (0, 0) in, every lane's transform visible
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         WDM_PTS(4);
         if (more) setup(mt2, nt2);
         WDM_PTS(5);
-        auto hook = [&]() __attribute__((always_inline)) { if (more) issue_head(TWO_PASS ? 0 : 1); };
+        auto hook = [&]() __attribute__((always_inline)) { if (more) issue_head(TWO_PASS ? 3 : 1); };
         WDM_RELOAD_ARGS();
         if constexpr (TWO_PASS) conv_epilogue<T, 16, TW, 4, WN, 2, decltype(hook), true>(*ap, acc, smem + ConvDmaPCfg::EPI_OFF, true, wave, lane, wave_m, wave_n, c_img0, c_oy0, c_ox0, c_n0, c_tile, 0, hook, false);
         else conv_epilogue<T, 16, TW, 4, WN, WN, decltype(hook), false>(*ap, acc, smem + ConvDmaPCfg::EPI_OFF, true, wave, lane, wave_m, wave_n, c_img0, c_oy0, c_ox0, c_n0, c_tile, 0, hook, false);
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         __builtin_amdgcn_sched_barrier(0);
         WDM_PTS(7);
         ++tile_it;
-        if constexpr (!TWO_PASS) issue_head(2);
+        if constexpr (!TWO_PASS) issue_head(2); else issue_head(4);
     }
 #undef WDM_DMA_SYNC
 #undef WDM_RELOAD_ARGS

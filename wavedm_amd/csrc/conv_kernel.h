@@ -83,6 +83,16 @@ struct ConvArgs {
     int grid_gn;           // XCD N-groups (1, 2, 4 or 8), see the kernel's tile mapping
     float* stats;          // optional: GroupNorm partial statistics of the output, float4[B][stats_nslab][Cout] (see elementwise.hip)
     int stats_nslab;       // slabs per image = tiles per image x wave tiles (in M) per tile
+    float* gst;            // optional, with stats: GROUP-level partials of the output, float[B][stats_nslab][32][3] = (pivot, sum(x-K), sum((x-K)^2)) over the
+                           // slab's rows x the group's Cout / 32 channels (4, 8 or 16: a group never straddles a wave's columns) -- what a consumer conv needs
+                           // to finalise GroupNorm in its own prologue (gn_inline.h) instead of a gn_finalize launch
+    // consumer side (LDS-DMA 3x3 kernels): pro != 0 with gin set = the GroupNorm of x0 (single input, Cin = 128 / 256 / 512) is finalised in the prologue from
+    // x0's group partials and the norm's weights; scale / shift are then unused
+    const float* gin;      // float[B][gin_nslab][32][3]
+    int gin_nslab;
+    const float* gn_gamma; // [Cin]
+    const float* gn_beta;  // [Cin]
+    float gn_eps;
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
                            //    (plain GEMMs over M rows that do not fill the last row of the 16-wide pixel grid)
@@ -526,6 +536,20 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 const int nn = ncol0 + col;
                 if ((r0 % SROWS) == 0 && nn < a.Cout && img_g < a.B)
                     ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, (float)SROWS);
+                if (a.gst != nullptr) {
+                    // group-level partials: the gs = Cout / 32 channels of a group are gs consecutive lanes (gs divides the pass's columns: host check);
+                    // re-centred on the group's first channel and summed by a fixed xor tree, explicit fma (every instantiation rounds alike)
+                    const int gs = a.Cout >> 5;
+                    const float Kg = __shfl(K, lane & ~(gs - 1));
+                    const float d = K - Kg, nr = (float)SROWS;
+                    float g1 = __builtin_fmaf(nr, d, s1);
+                    float g2 = __builtin_fmaf(nr * d, d, __builtin_fmaf(2.0f * d, s1, s2));
+                    for (int off = 1; off < gs; off <<= 1) { g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
+                    if ((r0 % SROWS) == 0 && (lane & (gs - 1)) == 0 && nn < a.Cout && img_g < a.B) {
+                        float* q = a.gst + (((long long)img_g * a.stats_nslab + slab) * 32 + nn / gs) * 3;
+                        q[0] = Kg; q[1] = g1; q[2] = g2;
+                    }
+                }
             }
         } else {
             // channel-major (NCHW) outputs and odd channel counts: lane = pixel row, loop over channels, so that
