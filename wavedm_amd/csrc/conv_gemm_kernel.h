@@ -184,7 +184,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         if (t == 123.456f) ((float*)a.y)[tid] = t;
         return;
     }
-    conv_epilogue<T, TH, TW, WM, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    // 8 x 8 maps (four images per tile): half-image statistics slabs need the two-fragment passes (conv_stat_rows)
+    conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : WN)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm
