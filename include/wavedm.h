@@ -196,7 +196,7 @@ int wdm_temb_forward(wdm_handle* h, const float* t, int n_t, int ch, const float
  * wdm_conv2d_direct: torch.nn.Conv2d(Cin, Cout, k, stride, pad, groups) (weight [Cout][Cin/groups][k][k]) or, transposed != 0,
  *   torch.nn.ConvTranspose2d(Cin, Cout, k, stride, pad) (weight [Cin][Cout][k][k]) -- unet.py:407-424 (q, k, v), :522, :567.
  * wdm_groupnorm: GroupNorm(32, eps) [+ SiLU] (unet.py:36-37; Attn_Global applies norm_patch to both inputs, :433-434).
- * wdm_cross_attention: q (B,C,Nq), k and v (B,C,Nk <= 64) -> out (B,C,Nq), softmax(C^-0.5 q^T k) over the keys (unet.py:438-455).
+ * wdm_cross_attention: q (B,C,Nq), k and v (B,C,Nk), any Nk >= 1 -> out (B,C,Nq), softmax(C^-0.5 q^T k) over the keys (unet.py:438-455).
  * wdm_upsample_add: y = x + nearest_upsample(hp, scale) (unet.py:459-462). */
 int wdm_conv2d_direct(wdm_handle* h, const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, int k,
                       int stride, int pad, int groups, int transposed, float* y, void* stream);

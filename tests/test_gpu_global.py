@@ -73,7 +73,7 @@ def test_global_operators_vs_torch():
         xd, gwd, gbd = x.cuda(), gw.cuda(), gb.cuda()
         _lib.check(L.wdm_groupnorm(h, p(xd), p(gwd), p(gbd), 2, 64, 6, 10, 1e-6, silu, p(y), st()))
         assert rel_linf(y.cpu(), want) <= 1e-5
-    for (B, Cc, nq, nk) in [(2, 32, 100, 5), (1, 64, 64, 64), (3, 8, 7, 1)]:
+    for (B, Cc, nq, nk) in [(2, 32, 100, 5), (1, 64, 64, 64), (3, 8, 7, 1), (2, 48, 130, 330), (1, 16, 64, 65)]:      # 330 keys: a 480 x 720 image's pooled tokens (key blocks of 64)
         q, k, v = seeded((B, Cc, nq), 7), seeded((B, Cc, nk), 8), seeded((B, Cc, nk), 9)
         wgt = F.softmax(torch.bmm(q.permute(0, 2, 1), k) * (Cc ** -0.5), dim=2)
         want = torch.bmm(v, wgt.permute(0, 2, 1))

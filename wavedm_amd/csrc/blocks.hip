@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include <atomic>
 #include <mutex>
 #include "common.h"
 #include "gn_inline.h"
@@ -79,23 +80,36 @@ static int alloc_f32(Ctx& c, size_t n, float** p) {
 
 // The sub-pixel Upsample kernel (conv_up4_kernel.h) takes bf16 maps whose LOW-resolution size is a multiple of its 16 x 16 tile, or 8 x 8 (four images per tile); WDM_UP4=0
 // keeps the 9-tap kernel everywhere (A/B runs)
-static EnvCfg g_env;
-static std::once_flag g_env_once;
+// The switches are read into a fresh EnvCfg and published through an atomic pointer: a launch path on another thread sees either the old or the new
+// set, never a half-written one (earlier configurations are kept alive: a reader may still hold a reference; a refresh is a test / A-B harness event).
+// wdm_env_refresh() must not be called with launches in flight on objects whose workspace was sized under other switches: wdm_unet_workspace_bytes is
+// re-queried by the Python layer per call; callers of the C ABI re-query after a refresh.
+static std::atomic<const EnvCfg*> g_env{nullptr};
+static std::mutex g_env_mu;
 void env_cfg_refresh() {
-    EnvCfg c;
+    EnvCfg* c = new EnvCfg();
     auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e ? (e[0] == '0' ? 0 : 1) : dflt; };
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    c.up4 = flag("WDM_UP4", 1); c.dma8 = flag("WDM_DMA8", 1); c.dma8_bn64 = num("WDM_DMA8_BN", 0) == 64; c.dma8_gn = num("WDM_DMA8_GN", 4);
-    c.wsm = flag("WDM_WSM", 1); c.dma32 = num("WDM_DMA32", 0); c.dma_pf = num("WDM_DMA_PF", 0) == 1; c.attn_fused = flag("WDM_ATTN_FUSED", 1);
-    c.attn_vt = flag("WDM_ATTN_VT", 1); c.fuse_nin = flag("WDM_FUSE_NIN", 1); c.gn_pass_hw = num("WDM_GN_PASS_HW", 64); c.grid_gn = num("WDM_GRID_GN", 1);
-    c.conv_dma = num("WDM_CONV_DMA", 1) != 0; c.gemm = flag("WDM_GEMM", 1); c.bn128 = flag("WDM_CONV_BN128", 1); c.wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c.gemm8 = flag("WDM_GEMM8", 0); c.gn_inline = flag("WDM_GN_INLINE", 1); c.up4_gn = num("WDM_UP4_GN", 1); c.gn_fused = flag("WDM_GN_FUSED", 1); c.persist = num("WDM_PERSIST", 1); c.persist_min = num("WDM_PERSIST_MIN", 100);
-    c.bn256 = num("WDM_BN256", 1); c.bn256_half = flag("WDM_BN256_HALF", 0);
-    g_env = c;
+    c->up4 = flag("WDM_UP4", 1); c->dma8 = flag("WDM_DMA8", 1); c->dma8_bn64 = num("WDM_DMA8_BN", 0) == 64; c->dma8_gn = num("WDM_DMA8_GN", 4);
+    c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
+    c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->grid_gn = num("WDM_GRID_GN", 1);
+    c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
+    c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
+    c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
+    c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    g_env.store(c, std::memory_order_release);
 }
 const EnvCfg& env_cfg() {
-    std::call_once(g_env_once, env_cfg_refresh);
-    return g_env;
+    const EnvCfg* c = g_env.load(std::memory_order_acquire);
+    if (!c) {
+        {
+            std::lock_guard<std::mutex> lk(g_env_mu);
+            c = g_env.load(std::memory_order_acquire);
+        }
+        if (!c) { env_cfg_refresh(); c = g_env.load(std::memory_order_acquire); }
+    }
+    return *c;
 }
 
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {

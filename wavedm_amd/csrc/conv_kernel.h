@@ -419,7 +419,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                     unsigned vo = vo_r;
                     if (a.m_valid != 0 && so_pix[it] + lane_pix >= a.m_valid) vo = OOBV;
                     if (RAGGED && it * RPI + lp >= EROWS) vo = OOBV;
-                    resv[it] = img_ok[it] ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vo, so_pix[it] * a.res_s * ES, 0)) : make_uint4(0u, 0u, 0u, 0u);
+                    resv[it] = img_ok[it] ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vo, (int)((unsigned)so_pix[it] * (unsigned)a.res_s * (unsigned)ES), 0)) : make_uint4(0u, 0u, 0u, 0u);      // unsigned: tensors up to 3.75 GB (conv_dispatch.inc)
                 }
             }
             // the lane's rows of the tile, all requested before the first is used (one LDS round trip for the pass instead of one per iteration)
@@ -453,7 +453,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                     float rf[8];
                     if (VEC == 8) TI<T>::unpack(resv[it], rf);
                     else {
-                        const int so = so_pix[it] * a.res_s * ES;
+                        const int so = (int)((unsigned)so_pix[it] * (unsigned)a.res_s * (unsigned)ES);
                         TI<T>::unpack(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vor, so, 0)), rf);
                         TI<T>::unpack(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vor + 16, so, 0)), rf + 4);
                     }
@@ -464,7 +464,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 // The uniform part is added to the lane's offset instead of riding in the store's scalar-offset field: a 16-byte buffer store with an
                 // SGPR soffset was seen (gfx950, fp32 tiles) to pick up a data register that the NEXT VALU instruction overwrote -- the compiler
                 // inserts the wait state for that hazard only when soffset is not a register.  (The loads above have no data operand to race on.)
-                const unsigned vst = voy == OOBV ? OOBV : voy + (unsigned)(so_pix[it] * a.y_s * es_y);
+                const unsigned vst = voy == OOBV ? OOBV : voy + (unsigned)so_pix[it] * (unsigned)a.y_s * (unsigned)es_y;
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 if (a.y_mode == Y_NHWC && VEC == 8) {
                     const uint4 pk = TI<T>::pack(v);

@@ -94,40 +94,60 @@ __global__ __launch_bounds__(256) void groupnorm_nchw_kernel(const float* __rest
     }
 }
 
-// Cross attention, Nk <= 64 keys: q [B][C][Nq], k / v [B][C][Nk] -> out [B][C][Nq];  w = softmax_j(C^-0.5 sum_c q[c][i] k[c][j]), out[c][i] = sum_j v[c][j] w[i][j]
-// One workgroup = 64 queries of one image; thread (qi, part) with 4 parts splitting the keys / channels.
+// Cross attention, any number of keys: q [B][C][Nq], k / v [B][C][Nk] -> out [B][C][Nq];  w = softmax_j(C^-0.5 sum_c q[c][i] k[c][j]), out[c][i] = sum_j v[c][j] w[i][j]
+// One workgroup = 64 queries of one image; thread (qi, part) with 4 parts splitting the keys / channels.  Keys go through in blocks of 64: a first sweep
+// keeps the running row maximum and the running sum of exp(s - max) (rescaled when the maximum moves), a second sweep recomputes the scores, normalises
+// them as softmax does and continues every output's fma chain over the keys in ascending order (out is the accumulator between blocks).  With one block
+// (Nk <= 64: every map the reference's own 64 x 64 `total` produces) the arithmetic is exactly the single-block form.
 __global__ __launch_bounds__(256) void cross_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int C, int Nq,
                                                               int Nk, float scale, float* __restrict__ out) {
     __shared__ float sc[64][65];
+    __shared__ float row_m[64], row_r[64];
     const int b = blockIdx.y, q0 = blockIdx.x * 64;
     const int qi = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int i = q0 + qi;
     const float* qb = q + (long long)b * C * Nq;
     const float* kb = k + (long long)b * C * Nk;
     const float* vb = v + (long long)b * C * Nk;
-    // scores: this thread owns keys j = part, part + 4, ...
-    for (int j = part; j < Nk; j += 4) {
-        float a = 0.f;
-        if (i < Nq)
-            for (int c = 0; c < C; ++c) a = fmaf(qb[(long long)c * Nq + i], kb[(long long)c * Nk + j], a);
-        sc[qi][j] = a * scale;
-    }
-    __syncthreads();
-    if (part == 0) {       // softmax over the row (fixed order)
-        float m = -INFINITY;
-        for (int j = 0; j < Nk; ++j) m = fmaxf(m, sc[qi][j]);
-        float s = 0.f;
-        for (int j = 0; j < Nk; ++j) { const float e = expf(sc[qi][j] - m); sc[qi][j] = e; s += e; }
-        const float r = 1.0f / s;
-        for (int j = 0; j < Nk; ++j) sc[qi][j] *= r;
-    }
-    __syncthreads();
-    if (i < Nq)
-        for (int c = part; c < C; c += 4) {
+    auto scores = [&](int j0, int nj) {        // this thread owns keys j = part, part + 4, ... of the block
+        for (int j = part; j < nj; j += 4) {
             float a = 0.f;
-            for (int j = 0; j < Nk; ++j) a = fmaf(vb[(long long)c * Nk + j], sc[qi][j], a);
-            out[((long long)b * C + c) * Nq + i] = a;
+            if (i < Nq)
+                for (int c = 0; c < C; ++c) a = fmaf(qb[(long long)c * Nq + i], kb[(long long)c * Nk + j0 + j], a);
+            sc[qi][j] = a * scale;
         }
+    };
+    float m = -INFINITY, ssum = 0.f;           // part 0: running maximum and sum of the row (fixed order)
+    for (int j0 = 0; j0 < Nk; j0 += 64) {
+        const int nj = min(64, Nk - j0);
+        scores(j0, nj);
+        __syncthreads();
+        if (part == 0) {
+            float mb = m;
+            for (int j = 0; j < nj; ++j) mb = fmaxf(mb, sc[qi][j]);
+            if (j0 > 0) ssum *= expf(m - mb);
+            m = mb;
+            for (int j = 0; j < nj; ++j) ssum += expf(sc[qi][j] - m);
+        }
+        __syncthreads();
+    }
+    if (part == 0) { row_m[qi] = m; row_r[qi] = 1.0f / ssum; }
+    __syncthreads();
+    for (int j0 = 0; j0 < Nk; j0 += 64) {
+        const int nj = min(64, Nk - j0);
+        if (Nk > 64) scores(j0, nj);           // one block: the scores of the first sweep are still there
+        __syncthreads();
+        if (part == 0)
+            for (int j = 0; j < nj; ++j) sc[qi][j] = expf(sc[qi][j] - row_m[qi]) * row_r[qi];
+        __syncthreads();
+        if (i < Nq)
+            for (int c = part; c < C; c += 4) {
+                float a = j0 ? out[((long long)b * C + c) * Nq + i] : 0.f;
+                for (int j = 0; j < nj; ++j) a = fmaf(vb[(long long)c * Nk + j0 + j], sc[qi][j], a);
+                out[((long long)b * C + c) * Nq + i] = a;
+            }
+        __syncthreads();
+    }
 }
 
 // y = x + nearest_upsample(h, s)         x, y: [B][C][H][W], h: [B][C][H/s][W/s]
@@ -174,7 +194,7 @@ int wdm_groupnorm(wdm_handle* h, const float* x, const float* gamma, const float
 
 int wdm_cross_attention(wdm_handle* h, const float* q, const float* k, const float* v, int B, int C, int Nq, int Nk, float* out, void* stream) {
     if (!h || !q || !k || !v || !out) WDM_FAIL(WDM_EINVAL, "wdm_cross_attention: null argument");
-    if (Nk < 1 || Nk > 64) WDM_FAIL(WDM_EINVAL, "wdm_cross_attention: %d keys (1 .. 64)", Nk);
+    if (Nk < 1) WDM_FAIL(WDM_EINVAL, "wdm_cross_attention: %d keys", Nk);
     const float scale = 1.0f / sqrtf((float)C);                                   // int(c) ** (-0.5), unet.py:445
     hipLaunchKernelGGL(cross_attention_kernel, dim3((Nq + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, q, k, v, C, Nq, Nk, scale, out);
     WDM_HIP(hipGetLastError());

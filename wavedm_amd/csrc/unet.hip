@@ -70,7 +70,9 @@ struct wdm_unet {
         params.push_back(p);
     }
     // cin_pad > cin: the kernels' K dimension is padded with zero columns (conv_in of a model whose input width is not a multiple of 32)
-    ConvD add_conv(const std::string& name, int cin, int cout, int k, int cin_pad = 0) {
+    // s1: a stride-1 conv -- the only 3x3 kind the LDS-DMA kernels take, hence the only one that gets the slab-major weight copy (Downsample / Upsample
+    // convs never read theirs: less to pack after every trainer sync, a smaller weight broadcast)
+    ConvD add_conv(const std::string& name, int cin, int cout, int k, int cin_pad = 0, bool s1 = true) {
         ConvD d{};
         if (cin_pad <= 0) cin_pad = cin;
         d.cin = cin_pad; d.cout = cout; d.k = k; d.rows_pad = conv_rows_pad(cout);
@@ -78,7 +80,7 @@ struct wdm_unet {
         d.b_off = take((size_t)cout * 4);
         add_param(name + ".weight", {cout, cin, k, k}, PK_CONV, d.w_off, d.rows_pad, 0);
         params.back().cin_dst = cin_pad != cin ? cin_pad : 0;
-        if (cin_pad == cin && conv_sm_eligible(cfg.dtype, k, cin)) {
+        if (s1 && cin_pad == cin && conv_sm_eligible(cfg.dtype, k, cin)) {
             d.sm_off = take(conv_packed_bytes(cin, cout, k, cfg.dtype));
             params.back().sm_off = d.sm_off;
         }
@@ -175,7 +177,7 @@ int wdm_unet::build() {
         if (is_attn(res))
             for (int b = 0; b < nrb; ++b) down_attn[l].push_back(add_attn("down." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != nres - 1) {
-            down_ds[l] = add_conv("down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3);
+            down_ds[l] = add_conv("down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3, 0, false);
             res /= 2;
         }
     }
@@ -193,7 +195,7 @@ int wdm_unet::build() {
         if (is_attn(res))
             for (int b = 0; b <= nrb; ++b) up_attn[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != 0) {
-            up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3);
+            up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3, 0, false);
             if (cfg.dtype == WDM_BF16 && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h, next to the 3x3 ones
                 up_us[l].up4_off = take((size_t)16 * up_us[l].rows_pad * block_in * 2);
                 params[index["up." + std::to_string(l) + ".upsample.conv.weight"]].up4_off = up_us[l].up4_off;

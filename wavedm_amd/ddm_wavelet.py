@@ -157,7 +157,8 @@ class DenoisingDiffusion_Wavelet(object):
         """Copy the trained (or EMA) weights back into the inference model."""
         sd = self.trainer.ema_state_dict() if ema else self.trainer.state_dict()
         self.model.load_state_dict(sd, strict=True)
-        self.model.pack_weights(force=True)
+        if hasattr(self.model, "pack_weights"):                                 # DiffusionUNet_Global packs per call (unet_global.py)
+            self.model.pack_weights(force=True)
 
     def train(self, DATASET, max_steps=None):
         """ddm_wavelet.py:200-292: epochs over DATASET.get_loaders()[0]; on rank 0 the validation sheet (`restore`, :273-278) every
@@ -187,6 +188,14 @@ class DenoisingDiffusion_Wavelet(object):
                     return
 
     # ---- sampling ----------------------------------------------------------------------------------
+    def _require_plain_unet(self, what):
+        """data.global_attn builds DiffusionUNet_Global, which only the use_global=True branch of the stitched sampler can drive (it needs `total`,
+        the whole image its patches attend to); the reference is equally unusable on the other paths (total=None reaches total.repeat,
+        ddm_wavelet.py:482) -- say so instead of failing deep inside the sampler."""
+        if getattr(self.config.data, "global_attn", False):
+            raise RuntimeError(f"{what}: the model was built with data.global_attn=True (DiffusionUNet_Global); use "
+                               "sample_image(..., total=<whole image>, use_global=True)")
+
     def sample_image(self, x_cond, x, x_other=None, last=True, patch_locs=None, patch_size=None, total=None,
                      use_global=False, use_other=False):
         """ddm_wavelet.py:295-309."""
@@ -213,6 +222,7 @@ class DenoisingDiffusion_Wavelet(object):
             raise NotImplementedError("only eta = 0 (DDIM) is used by the reference (ddm_wavelet.py:303)")
         if use_global:
             return self._ddim_overlapping_global(x, x_cond, list(seq), model, b, corners, p_size, total)
+        self._require_plain_unet("generalized_steps_overlapping(use_global=False)")
         if not use_other:
             x_other = None                                                      # ddm_wavelet.py:471-473: the UNet sees [x_cond | x_t] only
         if not self.config.data.begin_from_noise:                              # ddm_wavelet.py:445-447
@@ -329,6 +339,7 @@ class DenoisingDiffusion_Wavelet(object):
 
         rainy01 (B,3,4R,4R) in [0,1]; x_T (B,3,R,R) start noise; returns the restored (B,3,4R,4R) in [0,1] built
         from x0_preds[keep] like restoration.py:108-134, plus (xs[-1], x0_preds[keep])."""
+        self._require_plain_unet("restore_batch")
         x_cond = self.wavelet_dec.forward_affine(rainy01)                        # DWT(2x - 1): data_transform folded into the kernel
         hf = self.generator(rainy01) if hfrm_out01 is None else hfrm_out01
         hf_wav = x_cond if hf is rainy01 else self.wavelet_dec.forward_affine(hf)   # identity stand-in: the same tensor, not a second pass
