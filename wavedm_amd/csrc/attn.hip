@@ -7,7 +7,9 @@
 namespace wdm {
 
 bool attn_fused_eligible(int dtype, int N, int C) {
-    return env_cfg().attn_fused && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C;
+    // one phase-2 pass over <= 512 channels, two over the halves above that (the halves must be whole wave fragments: multiples of 128)
+    return env_cfg().attn_fused && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C &&
+           (C <= AttnFusedCfg::MAX_CP || (C / 2) % 128 == 0);
 }
 
 int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias) {

@@ -1,4 +1,4 @@
-// Fused single-head self-attention core for the 16 x 16 maps (N = 256 tokens, C = 64 ... 512 channels), bf16:
+// Fused single-head self-attention core for the 16 x 16 maps (N = 256 tokens, C = 128 ... 1024 channels), bf16:
 //     O[b][i][c] = sum_j softmax_j(C^-1/2 q[b][i] . k[b][j]) v[b][j][c]                                     (models/unet.py:176-189)
 // in ONE kernel instead of Q.K^T (GEMM, fp32 S to HBM) -> softmax_rows (S -> P) -> P.V (GEMM): S and P never leave the CU.
 //
@@ -17,6 +17,8 @@
 // Phase 2   O^T[channel][query] = V^T . P^T over the 256 keys in steps of 32: V^T rows are channels ([row][key] image, 64-byte rows in the conv
 //           kernel's rotated layout), P rows are queries (512-byte rows, unit slot ^ (row & 15)); ring of three 32 KB V^T chunks.  Waves = 8
 //           channel blocks of C / 8.  The transpose again leaves four consecutive CHANNELS of a query in a lane: 8-byte global stores.
+//           C > 512 (BASELINE configs[2]: the 768-channel AttnBlocks of the 128 x 128 model): phase 2 runs twice, over the lower and the upper half
+//           of the channels, from the same P (a 32-key chunk of all 768 rows would be 48 KB, three of them do not fit beside P).
 // The first V^T chunks are fetched while the softmax runs.  LDS: phase 1 3 x 40 KB; phase 2 P 32 KB + 3 x 32 KB; + 1 KB of statistics.
 #pragma once
 #include "conv_kernel.h"
@@ -37,8 +39,9 @@ struct AttnFusedCfg {
     static constexpr int N = 256, QB = 64, NTHREADS = 512;
     static constexpr int ST1 = (N + QB) * 128;                 // 40 KB: K rows then Q rows of one 64-channel step
     static constexpr int P_BYTES = QB * N * 2;                 // 32 KB
-    static constexpr int MAX_C = 512;
-    static constexpr int ST2 = MAX_C * 64;                     // 32 KB: C rows x 32 keys
+    static constexpr int MAX_CP = 512;                         // channels per phase-2 pass
+    static constexpr int MAX_C = 2 * MAX_CP;
+    static constexpr int ST2 = MAX_CP * 64;                    // 32 KB: rows of one pass x 32 keys
     static constexpr int RED_OFF = P_BYTES + 3 * ST2;          // 128 KB
     static constexpr int LDS_BYTES = RED_OFF + 2 * 4 * QB * 4;
     static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
@@ -89,20 +92,22 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
 #pragma unroll
         for (int j = 0; j < 5; ++j) dma16(q_qk, base + j * 1024, v1[j], step * 128);
     };
-    // ---- phase-2 DMA geometry: C / 16 pieces of 16 rows x 64 B per 32-key chunk (conv kernel's rotated 64-byte rows)
-    const int p2 = Cc / 16;                                            // pieces per chunk (<= 32)
+    // ---- phase-2 DMA geometry: Cp / 16 pieces of 16 rows x 64 B per 32-key chunk (conv kernel's rotated 64-byte rows); Cp = channels per pass
+    const int npass = Cc > C::MAX_CP ? 2 : 1;
+    const int Cp = Cc / npass;
+    const int p2 = Cp / 16;                                            // pieces per chunk (<= 32)
     const int un2 = (lane & 3) ^ ((lane >> 3) & 2);
     unsigned v2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int piece = wave * 4 + j;
-        const int row = piece * 16 + (lane >> 2);                      // channel
+        const int row = piece * 16 + (lane >> 2);                      // channel of the pass
         v2[j] = piece < p2 ? (unsigned)((((long long)b * Cc + row) * N) * 2 + un2 * 16) : 0xFFFF0000u;
     }
-    auto issue2 = [&](int chunk, int buf) __attribute__((always_inline)) {
+    auto issue2 = [&](int pass, int chunk, int buf) __attribute__((always_inline)) {
         const unsigned base = lds0 + C::P_BYTES + buf * C::ST2 + wave * (4 * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(q_vt, base + j * 1024, v2[j], chunk * 64);
+        for (int j = 0; j < 4; ++j) dma16(q_vt, base + j * 1024, v2[j], pass * Cp * N * 2 + chunk * 64);
     };
 
     // =========================== phase 1: S^T = K . Q^T ===========================
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                      // every wave is done with the phase-1 stages
     __builtin_amdgcn_sched_barrier(0);
-    issue2(0, 0);                                                      // the first V^T chunks travel while the softmax runs
-    issue2(1, 1);
+    issue2(0, 0, 0);                                                   // the first V^T chunks travel while the softmax runs
+    issue2(0, 1, 1);
 
     // =========================== softmax over the keys, per query ===========================
     // lane: query column wn*32 + j*16 + (lane & 15); keys wm*64 + i*16 + (lane >> 4)*4 + r
@@ -207,27 +212,35 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     (void)mx; (void)sm;
 
     // =========================== phase 2: O^T = V^T . P^T ===========================
-    // wave = block of C/8 channels; fragments: A = V^T rows (channels), B = P rows (queries); K = 32 keys per chunk
-    const int cw = Cc / 8;                                             // channels per wave: 8 ... 64
-    const int nfi = cw / 16;                                           // channel fragments per wave (C multiple of 128)
-    f32x4 o_acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wave = block of Cp/8 channels of the pass; fragments: A = V^T rows (channels), B = P rows (queries); K = 32 keys per chunk
+    const int cw = Cp / 8;                                             // channels per wave and pass: 16 ... 64
+    const int nfi = cw / 16;                                           // channel fragments per wave (Cp multiple of 128)
     const int va_off = C::P_BYTES + lds_off(wave * cw + (lane & 15), ku);                 // + i * 16 rows * 64 B
     int pb_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pb_off[j] = (j * 16 + (lane & 15)) * 512;                // + ((chunk*4 + ku) ^ (row & 15)) << 4
     const int prow15 = lane & 15;
-    {
+    T* op = (T*)a.o + ((long long)b * N + qb * QB) * Cc;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass > 0) {                                                // every wave is done with the ring: restart it on the upper half of the channels
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue2(pass, 0, 0);
+            issue2(pass, 1, 1);
+        }
+        f32x4 o_acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int buf = 0;
         for (int k = 0; k < N / 32; ++k) {
             if (k + 1 < N / 32) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // (k = 0: also makes every wave's P visible)
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 2 < N / 32) issue2(k + 2, buf >= 1 ? buf - 1 : 2);
+            if (k + 2 < N / 32) issue2(pass, k + 2, buf >= 1 ? buf - 1 : 2);
             const char* vb = smem + buf * C::ST2;
             uint4 af[4], bf[4];
 #pragma unroll
@@ -242,19 +255,18 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
                     for (int j = 0; j < 4; ++j) mma16<T>(o_acc[i][j], af[i], bf[j]);
             buf = buf == 2 ? 0 : buf + 1;
         }
+        // ---- epilogue of the pass: lane holds 4 consecutive channels (rows of the fragment) of query j*16 + (lane & 15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nfi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qn = j * 16 + (lane & 15);
+                    const int c0 = pass * Cp + wave * cw + i * 16 + (lane >> 4) * 4;
+                    const float4 vb = a.vbias ? *(const float4*)(a.vbias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0] + vb.x, o_acc[i][j][1] + vb.y), TI<T>::pack2(o_acc[i][j][2] + vb.z, o_acc[i][j][3] + vb.w));
+                }
     }
-    // ---- epilogue: lane holds 4 consecutive channels (rows of the fragment) of query j*16 + (lane & 15)
-    T* op = (T*)a.o + ((long long)b * N + qb * QB) * Cc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nfi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int qn = j * 16 + (lane & 15);
-                const int c0 = wave * cw + i * 16 + (lane >> 4) * 4;
-                const float4 vb = a.vbias ? *(const float4*)(a.vbias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0] + vb.x, o_acc[i][j][1] + vb.y), TI<T>::pack2(o_acc[i][j][2] + vb.z, o_acc[i][j][3] + vb.w));
-            }
 }
 
 }  // namespace wdm
