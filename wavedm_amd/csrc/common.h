@@ -193,6 +193,7 @@ struct EnvCfg {
     int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
+    int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)
     int gemm8 = 0;        // WDM_GEMM8=1: 1x1 convs on 8 x 8 maps (middle AttnBlock) on the LDS-DMA GEMM kernel, four images per tile -- measured 25.8 vs 22.4 us
                           // (768->768) and 23.0 vs 23.9 (768->1536): 96 / 192 workgroups of a 12-step K loop are latency, not staging
     int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
