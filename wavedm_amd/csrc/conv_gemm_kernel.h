@@ -35,8 +35,9 @@ struct GemmCfg {
     static constexpr int A_BYTES = M * 128;
     static constexpr int B_BYTES = BN * 128;
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * WN + 4) * 4;       // one-pass epilogue (whole 128-byte rows per wave)
-    static constexpr int NBUF = 3;                                  // LDS ring: two stages in flight while one is consumed
+    static constexpr int EPI_NJ = WN > 4 ? 4 : WN;                  // epilogue passes of 64 columns (whole 128-byte rows per wave)
+    static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * EPI_NJ + 4) * 4;
+    static constexpr int NBUF = WN > 4 ? 2 : 3;                     // LDS ring: two stages in flight while one is consumed (256-column tiles: 64 KB stages, one in flight)
     static constexpr int LDS_BYTES = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
     static constexpr int A_CPW = (M / 8) / NWAVES;                  // 1 KB chunks (8 rows) per wave per stage
     static constexpr int B_CPW = (BN / 8) / NWAVES;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         a_off[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
         b_off[ks] = A_BYTES + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
     }
+    static_assert(C::NBUF == 3 || C::NBUF == 2, "ring of three (two stages of lead) or two (one)");
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -146,30 +148,35 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     const int nk = a.Cin / C::BK;
     constexpr int CPW = A_CPW + B_CPW;
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    if (C::NBUF == 3 && nk > 1) issue(1, 1);
     int buf = 0;
     for (int k = 0; k < nk; ++k) {
-        if (k + 1 < nk && !(WDM_GABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+        if (C::NBUF == 3 && k + 1 < nk && !(WDM_GABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < nk && !(WDM_GABL & 4)) issue(k + 2, buf >= 1 ? buf - 1 : C::NBUF - 1);      // (buf + 2) % 3
+        if (C::NBUF == 3) { if (k + 2 < nk && !(WDM_GABL & 4)) issue(k + 2, buf >= 1 ? buf - 1 : C::NBUF - 1); }      // (buf + 2) % 3
+        else if (k + 1 < nk) issue(k + 1, buf ^ 1);                                                                // the buffer stage k - 1 was read from
         const char* base = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // see conv_dma_kernel.h
-            uint4 af[WM], bfr[WN];
+            uint4 af[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a_off[ks] + i * (16 * 128));
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(base + b_off[ks] + j * (16 * 128));
+            for (int h = 0; h < WN / 4; ++h) {
+                uint4 bfr[4];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int j = 0; j < 4; ++j) bfr[j] = *(const uint4*)(base + b_off[ks] + (h * 4 + j) * (16 * 128));
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    if (WDM_GABL & 2) acc[i][j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
-                    else mma16t<T>(acc[i][j], af[i], bfr[j]);
-                }
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (WDM_GABL & 2) acc[i][h * 4 + j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
+                        else mma16t<T>(acc[i][h * 4 + j], af[i], bfr[j]);
+                    }
+            }
         }
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
     }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
         return;
     }
     // 8 x 8 maps (four images per tile): half-image statistics slabs need the two-fragment passes (conv_stat_rows)
-    conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : WN)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : C::EPI_NJ)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm
