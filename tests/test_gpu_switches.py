@@ -139,3 +139,16 @@ def test_groupnorm_finalised_in_the_conv_prologue_agrees_with_gn_finalize(gu, c,
     assert torch.equal(y, gu.resblock(sd, "rb", x, None, t, "bf16"))                # deterministic
     for env in ({"WDM_BN256": "0"}, {"WDM_BN256": "2"}, {"WDM_PERSIST": "2", "WDM_PERSIST_MIN": "1"}, {"WDM_PERSIST": "1", "WDM_PERSIST_MIN": "1"}, {"WDM_DMA32": "2"}):
         assert torch.equal(y, _with(env, lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))), env      # every tiling finalises alike
+
+
+def test_paired_gemm_launch_gives_the_same_bits(gu):
+    """The AttnBlock's q|k projection and V^T GEMM in ONE launch (conv_gemm_pair_kernel) == two launches (WDM_GEMM_PAIR=0)."""
+    for C, B in ((512, 5), (768, 2), (256, 3)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("at", shapes)
+        x = gu.seeded((B, C, 16, 16), 9)
+        y = _with({"WDM_GEMM_PAIR": "1"}, lambda: gu.attn(sd, "at", x, "bf16"))
+        assert torch.isfinite(y).all() and torch.equal(y, _with({"WDM_GEMM_PAIR": "0"}, lambda: gu.attn(sd, "at", x, "bf16")))

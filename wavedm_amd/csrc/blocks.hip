@@ -94,7 +94,7 @@ void env_cfg_refresh() {
     c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
     c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->grid_gn = num("WDM_GRID_GN", 1);
     c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
+    c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
     c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
     c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
@@ -119,12 +119,15 @@ bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s) {
     return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
 }
+int launch_gemm_pair(const ConvArgs& a, const ConvArgs& b, int dtype, hipStream_t s) {
+    return dtype == WDM_BF16 ? launch_gemm_pair_bf16(a, b, s) : dtype == WDM_F32X3 ? launch_gemm_pair_f32x3(a, b, s) : launch_gemm_pair_f32(a, b, s);
+}
 
 // ---- one fused convolution ---------------------------------------------------------------------
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
              int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats, const ConvW* shortcut,
-             const Tens* sx0, const Tens* sx1, const NormW* gn_inl) {
+             const Tens* sx0, const Tens* sx1, const NormW* gn_inl, ConvArgs* defer) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -184,6 +187,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         if (want_gst) { out->gst = (float*)((char*)out->stats + sb); a.gst = out->gst; }
     }
     if (c.dry) return WDM_OK;
+    if (defer) { *defer = a; return WDM_OK; }        // the caller launches it (together with another: launch_gemm_pair)
     return launch_conv(a, mode, c.dtype, c.s);
 }
 
@@ -329,11 +333,15 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     Tens hn;
     WDM_TRY(materialize_gn(c, w.n, x, nullptr, 0, &hn));
 
+    const bool fused = attn_fused_eligible(c.dtype, N, C);
+    // q|k projection and V^T (below) read the same map and are independent: one launch for both where the GEMM kernel takes them (launch_gemm_pair)
+    const bool pair = fused && env_cfg().attn_vt != 0 && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C && env_cfg().gemm_pair;
     Tens qk;
-    WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));   // [B][N][2C]
+    ConvArgs a_qk{};
+    WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr, false, nullptr, nullptr, nullptr, nullptr,
+                     pair ? &a_qk : nullptr));                                                                      // [B][N][2C]
     void* vT = c.ar->alloc((size_t)c.B * C * N * es);                                                               // [B][C][N]
     if (!vT) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention V^T)");
-    const bool fused = attn_fused_eligible(c.dtype, N, C);
     // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
     // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
@@ -349,7 +357,8 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
             a.w_bytes = (unsigned)((size_t)N * hn.xs * es);
             a.alpha = 1.0f;
             a.y = vT; a.y_mode = Y_NHWC; a.y_s = N;
-            WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
+            if (pair) WDM_TRY(launch_gemm_pair(a_qk, a, c.dtype, c.s));
+            else WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
         }
     } else {
         Tens dummy;

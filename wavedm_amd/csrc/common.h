@@ -193,6 +193,8 @@ struct EnvCfg {
     int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
+    int gemm_pair = 0;    // WDM_GEMM_PAIR=1: the AttnBlock's q|k and V^T GEMMs in one launch (same bits; measured +-0.1 %: 256 + 128 workgroups of 160 KB
+                          // LDS each still run one after the other on the 256 CUs, only a kernel boundary is saved)
     int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)
     int gemm8 = 0;        // WDM_GEMM8=1: 1x1 convs on 8 x 8 maps (middle AttnBlock) on the LDS-DMA GEMM kernel, four images per tile -- measured 25.8 vs 22.4 us
                           // (768->768) and 23.0 vs 23.9 (768->1536): 96 / 192 workgroups of a 12-step K loop are latency, not staging
@@ -205,13 +207,16 @@ void env_cfg_refresh();
 
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
+// two independent 1x1 convs / batched GEMMs, in one launch where the kernels allow it (conv_gemm_kernel.h: conv_gemm_pair_kernel)
+int launch_gemm_pair(const ConvArgs& a, const ConvArgs& b, int dtype, hipStream_t s);
 
 // ---- blocks (blocks.hip) ----------------------------------------------------------------------
 // want_stats: also emit the GroupNorm partial statistics of the output (out->stats) from the conv epilogue
 // gn_inl: GroupNorm(+SiLU) of the single input x0 finalised in the conv's own prologue from x0.gst (gn_inline.h); scale / shift are then null
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
-             bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr);
+             bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr,
+             ConvArgs* defer = nullptr);      // defer: fill *defer instead of launching (launch_gemm_pair)
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
 int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);

@@ -45,12 +45,12 @@ struct GemmCfg {
     static_assert((M / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "chunks must split evenly over the waves");
 };
 
+// the workgroup's work: block `bid` of the launch described by `a` (a kernel may hold two launches: conv_gemm_pair_kernel)
 template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid, char* smem) {
     using C = GemmCfg<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
     using T = __bf16;
     constexpr int BN = C::BN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
     // workgroup -> (M tile, N tile): same XCD-aware order as conv_kernel
-    const int bid = blockIdx.x;
     int mt, nt;
     if (!conv_decode_tile(a, bid, mt, nt)) return;
     const int n0 = nt * BN;
@@ -193,6 +192,22 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     }
     // 8 x 8 maps (four images per tile): half-image statistics slabs need the two-fragment passes (conv_stat_rows)
     conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : C::EPI_NJ)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+}
+
+template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_gemm_body<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>(a, blockIdx.x, smem);
+}
+
+// TWO independent GEMMs in one launch: blocks [0, nblk0) work on a0 (wave tiles of WN0 fragments), the rest on a1 -- the AttnBlock's q|k projection and
+// its V^T = W_v . h^T read the same normalised map and neither fills more than one round of workgroups, so side by side they share one launch, one
+// fill and one drain of the chip.  nblk0 is a multiple of 8 (XCD-aware tile order of either grid).
+template <int WN0, int WN1>
+__global__ __launch_bounds__(512, 2) void conv_gemm_pair_kernel(const ConvArgs a0, const ConvArgs a1, const int nblk0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nblk0) conv_gemm_body<16, 16, 1, 4, 2, 4, WN0>(a0, blockIdx.x, smem);
+    else conv_gemm_body<16, 16, 1, 4, 2, 4, WN1>(a1, blockIdx.x - nblk0, smem);
 }
 
 }  // namespace wdm
