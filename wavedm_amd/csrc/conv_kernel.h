@@ -93,6 +93,7 @@ struct ConvArgs {
     const float* gn_gamma; // [Cin]
     const float* gn_beta;  // [Cin]
     float gn_eps;
+    int no_direct;         // 1: statistics through the LDS column pass even where the epilogue could take them from the accumulators (WDM_EPI_DIRECT=0)
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
                            //    (plain GEMMs over M rows that do not fill the last row of the 16-wide pixel grid)
@@ -319,7 +320,9 @@ struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
 template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
                                                 int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
-                                                bool entry_barrier = true) {
+                                                bool entry_barrier = true, bool pre_applied = false) {
+    // pre_applied: the tile already holds the FINAL values (alpha * acc + bias + temb, no residual) and the statistics are written (conv_epilogue's
+    // direct path): rows are only rounded and stored
     constexpr int VEC = TI<T>::VEC;
     constexpr int ES = 16 / VEC;                           // bytes per element of T
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);   // 16-column fragments per pass (NJ_ = WN: one pass, whole 128-byte rows per wave)
@@ -340,7 +343,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
     constexpr int NPASS = (WN + NJ - 1) / NJ;
     static_assert((TH * TW) % EROWS == 0 || EROWS % (TH * TW) == 0, "wave tile vs image geometry");
     float add8[NPASS][8];
-    if (vec_ok && active) {
+    if (vec_ok && active && !pre_applied) {
         const int img_w = img0 + (wave_m * EROWS) / (TH * TW);
         const long long trow = (a.temb != nullptr && a.temb_per_image) ? (img_w < a.B ? img_w : a.B - 1) : 0;
         constexpr bool ONE_IMG = (TH * TW) % EROWS == 0;         // else (8x8 tiles, 128-row wave tiles) temb stays in the row loop
@@ -394,7 +397,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
             for (int e = 0; e < 8; ++e) bias8[e] = add8[jp / NJ][e];
             // GroupNorm partial statistics of the values as stored (optional): the final values go back into the LDS tile
             // and a column pass (lane = channel) sums them -- no cross-lane shuffles
-            const bool do_stats = a.stats != nullptr;
+            const bool do_stats = a.stats != nullptr && !pre_applied;
             constexpr int NIT = (EROWS + RPI - 1) / RPI;
             constexpr bool RAGGED = EROWS % RPI != 0;              // fewer rows than one iteration covers (16-row wave tiles): the lanes past them idle
             int so_pix[NIT];
@@ -442,9 +445,11 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 if (!row_ok) { voy = OOBV; vor = OOBV; }
                 const float4 v0 = tl[it][0], v1 = tl[it][1];
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (!pre_applied) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * a.alpha + bias8[e];
-                if (!TEMB_IN_ADD && a.temb != nullptr && ncol) {
+                    for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], a.alpha, bias8[e]);       // explicit: the direct path (conv_epilogue) computes the same
+                }
+                if (!pre_applied && !TEMB_IN_ADD && a.temb != nullptr && ncol) {
                     const float* tp = a.temb + (long long)(a.temb_per_image ? img_it[it] : 0) * a.temb_ld + n;
                     const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
                     v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
@@ -593,6 +598,100 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
     constexpr int ESTR = 16 * NJ + 4;
+    // ---- direct path (convs WITHOUT a residual operand that emit statistics: conv1 of every ResnetBlock, conv2 with the fused shortcut, Down / Upsample,
+    // conv_in): the final values alpha * acc + bias + temb are formed in the accumulator layout -- a lane holds 4 consecutive channels of one pixel --,
+    // and the GroupNorm partial statistics come straight from them: per slab the pivot is the value of the slab's first pixel, a lane sums its fragments'
+    // rows, a fixed xor tree joins the 16 pixel lanes.  The LDS tile then carries final values and the row loop only rounds and stores: no write-back of
+    // the rounded values, no column pass over the tile (of the 7.7 k ticks of a 256 x 128 tile's epilogue the column pass was 2.4 k, the write-back ~0.6 k).
+    // Convs with a residual need the row layout for its 16-byte loads and keep the column pass.
+    // MEASURED (round 3): -3.5 % end to end (576 / 582 vs 600 / 601 img/s at 20 steps; -4.3 % with ds_bpermute shuffles instead of the DPP rotations): in the
+    // column pass a lane IS a channel -- 64 independent LDS reads and three VALU per row, no cross-lane step --, here every value costs a rounding round trip
+    // and every channel a 16-lane reduction.  Off by default (WDM_EPI_DIRECT=1); every test passes with it on.
+    constexpr int EROWS_ = 16 * WM;
+    constexpr bool ONE_IMG_ = (TH * TW) % EROWS_ == 0;
+    constexpr int SROWS_ = conv_stat_rows(TH, TW, EROWS_);
+    bool direct = false;
+    if constexpr (ONE_IMG_ && SROWS_ % 16 == 0 && EROWS_ % SROWS_ == 0) {
+        direct = active && !a.no_direct && a.stats != nullptr && a.res == nullptr && a.m_valid == 0 && (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
+        if (direct) {
+            constexpr int FPS = SROWS_ / 16, NSL = EROWS_ / SROWS_, SPT = (TH * TW) / SROWS_;
+            const int img_w = img0 + (wave_m * EROWS_) / (TH * TW);
+            const long long trow = (a.temb != nullptr && a.temb_per_image) ? (img_w < a.B ? img_w : a.B - 1) : 0;
+            const int gs = a.Cout >> 5;
+            const int quad = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wave_n * WN + j) * 16 + quad * 4;                  // this lane's 4 consecutive channels of fragment column j
+                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < a.Cout) {
+                    if (a.bias != nullptr) ad = *(const float4*)(a.bias + n);
+                    if (a.sbias != nullptr) { const float4 c = *(const float4*)(a.sbias + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
+                    if (a.temb != nullptr) { const float4 c = *(const float4*)(a.temb + trow * a.temb_ld + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
+                }
+                const float add[4] = {ad.x, ad.y, ad.z, ad.w};
+                float vr[WM][4];                                                       // the values as the consumer will read them back
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], a.alpha, add[r]);
+                    if (a.y_mode == Y_NHWC && TI<T>::VEC == 8) {
+                        const unsigned p0 = TI<__bf16>::pack2(acc[i][j][0], acc[i][j][1]), p1 = TI<__bf16>::pack2(acc[i][j][2], acc[i][j][3]);
+                        vr[i][0] = __uint_as_float(p0 << 16); vr[i][1] = __uint_as_float(p0 & 0xffff0000u);
+                        vr[i][2] = __uint_as_float(p1 << 16); vr[i][3] = __uint_as_float(p1 & 0xffff0000u);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vr[i][r] = acc[i][j][r];
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    float K[4], s1[4], s2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        K[r] = __shfl(vr[sl * FPS][r], lane & 48);                      // the slab's first pixel (pixel lane 0 of its first fragment)
+#pragma unroll
+                        for (int f = 0; f < FPS; ++f) {
+                            const float d = vr[sl * FPS + f][r] - K[r];
+                            if (f == 0) { s1[r] = d; s2[r] = d * d; } else { s1[r] += d; s2[r] = __builtin_fmaf(d, d, s2[r]); }
+                        }
+                        // all-reduce over the 16 pixel lanes of the row by DPP rotations (one VALU each; __shfl_xor is a ds_bpermute round trip: measured
+                        // -4 % end to end in the first version of this path); only pixel lane 0's total is used, so the order is fixed
+                        s1[r] += dpp_row_ror<1>(s1[r]); s2[r] += dpp_row_ror<1>(s2[r]);
+                        s1[r] += dpp_row_ror<2>(s1[r]); s2[r] += dpp_row_ror<2>(s2[r]);
+                        s1[r] += dpp_row_ror<4>(s1[r]); s2[r] += dpp_row_ror<4>(s2[r]);
+                        s1[r] += dpp_row_ror<8>(s1[r]); s2[r] += dpp_row_ror<8>(s2[r]);
+                    }
+                    const int m0 = wave_m * EROWS_ + sl * SROWS_;
+                    const int img_g = img0 + m0 / (TH * TW);
+                    const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS_ + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
+                    const bool wr = (lane & 15) == 0 && n < a.Cout && img_g < a.B;
+                    if (wr) {
+                        float4* q = (float4*)a.stats + ((long long)img_g * a.stats_nslab + slab) * a.Cout + n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) q[r] = make_float4(K[r], s1[r], s2[r], (float)SROWS_);
+                    }
+                    if (a.gst != nullptr) {
+                        // group-level partials (gn_inline.h): a group's gs = 4 / 8 / 16 channels are this lane's four and those of 1 / 2 / 4 quadrant lanes
+                        const float Kg = __shfl(K[0], (lane & 15) | ((quad & ~((gs >> 2) - 1)) << 4));
+                        const float nr = (float)SROWS_;
+                        float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = K[r] - Kg;
+                            const float t1 = __builtin_fmaf(nr, d, s1[r]), t2 = __builtin_fmaf(nr * d, d, __builtin_fmaf(2.0f * d, s1[r], s2[r]));
+                            if (r == 0) { g1 = t1; g2 = t2; } else { g1 += t1; g2 += t2; }
+                        }
+                        if (gs >= 8) { g1 += __shfl_xor(g1, 16); g2 += __shfl_xor(g2, 16); }
+                        if (gs >= 16) { g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32); }
+                        if (wr && (quad & ((gs >> 2) - 1)) == 0) {
+                            float* q = a.gst + (((long long)img_g * a.stats_nslab + slab) * 32 + n / gs) * 3;
+                            q[0] = Kg; q[1] = g1; q[2] = g2;
+                        }
+                    }
+                }
+            }
+        }
+    }
     auto write_pass = [&](float* ep, int jp) __attribute__((always_inline)) {      // [channel][pixel] fragments -> ep[pixel][channel]
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
@@ -600,7 +699,8 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
             for (int i = 0; i < WM; ++i)
                 *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
-    conv_epilogue_w<T, TH, TW, WM, WN, NJ_, decltype(write_pass)&, Hook, CANON>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, entry_barrier);
+    conv_epilogue_w<T, TH, TW, WM, WN, NJ_, decltype(write_pass)&, Hook, CANON>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, entry_barrier,
+                                                                                direct);
     WDM_ETS(5);
 #ifdef WDM_EPI_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
