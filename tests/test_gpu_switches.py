@@ -152,3 +152,19 @@ def test_paired_gemm_launch_gives_the_same_bits(gu):
         x = gu.seeded((B, C, 16, 16), 9)
         y = _with({"WDM_GEMM_PAIR": "1"}, lambda: gu.attn(sd, "at", x, "bf16"))
         assert torch.isfinite(y).all() and torch.equal(y, _with({"WDM_GEMM_PAIR": "0"}, lambda: gu.attn(sd, "at", x, "bf16")))
+
+
+def test_proj_out_fused_into_the_attention_core_gives_the_same_bits(gu):
+    """attn_fused_kernel<PROJ>: proj_out (+ bias, + the block's input, + the statistics of the result) as a third phase of the attention kernel ==
+    the stand-alone GEMM (WDM_ATTN_PROJ=0): the same MFMA sequence per output and the same epilogue."""
+    for C, B in ((512, 5), (256, 3), (128, 9)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("at", shapes)
+        x = gu.seeded((B, C, 16, 16), 9)
+        y = gu.attn(sd, "at", x, "bf16")
+        y0 = _with({"WDM_ATTN_PROJ": "0"}, lambda: gu.attn(sd, "at", x, "bf16"))
+        assert torch.isfinite(y).all() and torch.equal(y, y0), C
+        assert rel_linf(y, gu.attn(sd, "at", x, "f32")) <= gu.TOL["bf16"]

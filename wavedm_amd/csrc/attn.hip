@@ -12,9 +12,12 @@ bool attn_fused_eligible(int dtype, int N, int C) {
            (C <= AttnFusedCfg::MAX_CP || (C / 2) % 128 == 0);
 }
 
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias) {
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias, const ConvArgs* proj) {
     using Cf = AttnFusedCfg;
-    if (!qk || !vT || !o || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
+    if (!qk || !vT || (!o && !proj) || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
+    if (proj && (C > 512 || proj->Cout != C || proj->Cin != C || proj->Hout != 16 || proj->Wout != 16 || proj->B != B || !proj->w || proj->w_bytes == 0 || proj->y_mode != Y_NHWC ||
+                 proj->temb || proj->m_valid || proj->up4 || (proj->stats && proj->stats_nslab != 4)))
+        WDM_FAIL(WDM_EINVAL, "attn(fused): proj_out epilogue arguments do not describe a C = %d 1x1 conv on 16 x 16 maps", C);
     const double qkb = (double)B * Cf::N * 2.0 * C * 2.0, vtb = (double)B * C * Cf::N * 2.0;
     if (qkb >= 4294901760.0) WDM_FAIL(WDM_EINVAL, "attn(fused): q|k tensor exceeds the 4 GB buffer-offset range");
     AttnFusedArgs a{};
@@ -25,16 +28,21 @@ int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hip
     int dev = 0;
     WDM_HIP(hipGetDevice(&dev));
     if (!(devs.load() & (1u << (dev & 31)))) {
-        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
+        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
+        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         devs.fetch_or(1u << (dev & 31));
     }
     const bool prof = prof_enabled();
     if (prof) {
         char name[96];
-        snprintf(name, sizeof(name), "attn_fused_n256_bf16|16x16 C=%d", C);
-        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C, (double)B * Cf::N * C * 2.0 * 4.0);
+        snprintf(name, sizeof(name), "attn_fused_n256_bf16|16x16 C=%d%s", C, proj ? " +proj" : "");
+        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
+                   (double)B * Cf::N * C * 2.0 * (proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0));
     }
-    hipLaunchKernelGGL(attn_fused_kernel, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a);      // 8 images x 4 query blocks per group of 32
+    ConvArgs pe{};
+    if (proj) { pe = *proj; pe.no_direct = 1; }
+    if (proj) hipLaunchKernelGGL(attn_fused_kernel<true>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
+    else hipLaunchKernelGGL(attn_fused_kernel<false>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
     if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());
     return WDM_OK;

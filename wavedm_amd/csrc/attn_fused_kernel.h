@@ -35,6 +35,11 @@ struct AttnFusedArgs {
     unsigned qk_bytes, vt_bytes;
 };
 
+// PROJ = true (C <= 512): proj_out (models/unet.py:189-191: 1x1 conv over the attention output, + bias, + the block's input) runs as a third phase on
+// the workgroup's own 64 queries -- Y^T[co][q] = W_p . O^T over the channels in chunks of 32, W_p streamed through the V^T ring like V^T was, O kept in
+// LDS as the bf16 image the GEMM would have read from HBM -- and leaves through conv_epilogue: the accumulator layout is the conv kernels' (a lane
+// holds 4 consecutive output channels of one query = pixel), a query block is one 64-row statistics slab of the 16 x 16 map.  Same MFMA sequence per
+// output and same epilogue as the stand-alone GEMM, hence the same bits; one 22 us launch and the O round trip through HBM gone per AttnBlock.
 struct AttnFusedCfg {
     static constexpr int N = 256, QB = 64, NTHREADS = 512;
     static constexpr int ST1 = (N + QB) * 128;                 // 40 KB: K rows then Q rows of one 64-channel step
@@ -47,7 +52,8 @@ struct AttnFusedCfg {
     static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-__global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a) {
+template <bool PROJ>
+__global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a, const ConvArgs pe) {
     using C = AttnFusedCfg;
     using T = __bf16;
     constexpr int N = C::N, QB = C::QB;
@@ -256,6 +262,13 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
             buf = buf == 2 ? 0 : buf + 1;
         }
         // ---- epilogue of the pass: lane holds 4 consecutive channels (rows of the fragment) of query j*16 + (lane & 15)
+        if constexpr (PROJ) {
+            // every wave is done with P and the ring: the first two W_p chunks go out, and O (bf16, as the GEMM would have read it) goes to LDS as
+            // 16 planes of [64 queries][32 channels] in the conv kernels' rotated 64-byte rows
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < nfi)
@@ -264,8 +277,64 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
                     const int qn = j * 16 + (lane & 15);
                     const int c0 = pass * Cp + wave * cw + i * 16 + (lane >> 4) * 4;
                     const float4 vb = a.vbias ? *(const float4*)(a.vbias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *(uint2*)(op + (long long)qn * Cc + c0) = make_uint2(TI<T>::pack2(o_acc[i][j][0] + vb.x, o_acc[i][j][1] + vb.y), TI<T>::pack2(o_acc[i][j][2] + vb.z, o_acc[i][j][3] + vb.w));
+                    const uint2 ov = make_uint2(TI<T>::pack2(o_acc[i][j][0] + vb.x, o_acc[i][j][1] + vb.y), TI<T>::pack2(o_acc[i][j][2] + vb.z, o_acc[i][j][3] + vb.w));
+                    if constexpr (PROJ) *(uint2*)(smem + (c0 >> 5) * (QB * 64) + lds_off(qn, (c0 & 31) >> 3) + ((c0 >> 2) & 1) * 8) = ov;
+                    else *(uint2*)(op + (long long)qn * Cc + c0) = ov;
                 }
+    }
+    if constexpr (PROJ) {
+        // =========================== phase 3: Y^T = W_p . O^T, then the conv epilogue ===========================
+        constexpr int O_BYTES = QB * 512 * 2;                              // 64 KB: the image of 512 channels (C <= 512: host check)
+        constexpr int ST3 = 512 * 64;                                      // 32 KB: W_p rows (output channels) x 32 input channels
+        static_assert(O_BYTES + 3 * ST3 <= 160 * 1024, "LDS");
+        const i32x4 q_w = make_q(pe.w, pe.w_bytes);
+        unsigned v3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j;
+            const int row = piece * 16 + (lane >> 2);                      // output channel
+            v3[j] = row < pe.w_rows && row < Cc ? (unsigned)(row * pe.w_row_stride * 2 + un2 * 16) : 0xFFFF0000u;
+        }
+        auto issue3 = [&](int chunk, int buf) __attribute__((always_inline)) {
+            const unsigned base = lds0 + O_BYTES + buf * ST3 + wave * (4 * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma16(q_w, base + j * 1024, v3[j], chunk * 64);
+        };
+        issue3(0, 0);
+        issue3(1, 1);
+        f32x4 y_acc[4][4];                                                 // [query block][channel block]: conv_epilogue's acc[i][j]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int wa_off = O_BYTES + lds_off(wave * 64 + (lane & 15), ku);             // + j * 16 rows * 64 B: W_p rows of this wave's 64 output channels
+        const int ob_off = lds_off(lane & 15, ku);                                      // + i * 16 rows * 64 B + chunk plane
+        const int nch = Cc / 32;
+        int buf = 0;
+        for (int k = 0; k < nch; ++k) {
+            if (k + 1 < nch) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // (k = 0: also makes every wave's part of the O image visible)
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < nch) issue3(k + 2, buf >= 1 ? buf - 1 : 2);
+            const char* wb = smem + buf * ST3;
+            const char* ob = smem + k * (QB * 64);
+            uint4 wf[4], of[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + wa_off + j * (16 * 64));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) of[i] = *(const uint4*)(ob + ob_off + i * (16 * 64));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16t<T>(y_acc[i][j], of[i], wf[j]);       // weight fragment = row operand: [channel][query] result (conv_kernel.h)
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // every wave is done with the operand images the epilogue tile overlays
+        __builtin_amdgcn_sched_barrier(0);
+        // the workgroup's 64 queries are rows 4 qb ... 4 qb + 3 of the image's 16 x 16 map: wave row `qb` of a 256-pixel tile; its 8 waves are 8 column blocks
+        conv_epilogue<T, 16, 16, 4, 4, 4>(pe, y_acc, smem, true, wave, lane, qb, wave, b, 0, 0, 0, 0, 0, EpiNoHook(), false);
     }
 }
 

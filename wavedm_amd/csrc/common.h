@@ -168,7 +168,9 @@ inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int
 // ---- fused attention core (attn.hip / attn_fused_kernel.h): qk [B][256][2C], vT [B][C][256] -> o [B][256][C], bf16
 bool attn_fused_eligible(int dtype, int N, int C);
 // vbias != nullptr: vT was computed without the v bias, which is added to the output instead
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr);
+// proj != nullptr (C <= 512): proj_out fused in as a third phase; *proj = the 1x1 conv's arguments as run_conv builds them (weights, bias, residual, output,
+// statistics); o is then unused
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr, const ConvArgs* proj = nullptr);
 
 // ---- experiment switches (environment), read ONCE -- at first use or when wdm_env_refresh() is called (tests and A/B harnesses that change the
 // environment inside a running process call it); no launch path calls getenv.  Defaults are the measured best.
@@ -193,6 +195,7 @@ struct EnvCfg {
     int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
+    int attn_proj = 1;    // WDM_ATTN_PROJ=0: proj_out of the AttnBlocks as its own GEMM launch
     int epi_direct = 0;   // WDM_EPI_DIRECT=1: GroupNorm partial statistics of residual-free convs straight from the accumulators (measured 3.5 % slower)
     int gemm_pair = 0;    // WDM_GEMM_PAIR=1: the AttnBlock's q|k and V^T GEMMs in one launch (same bits; measured +-0.1 %: 256 + 128 workgroups of 160 KB
                           // LDS each still run one after the other on the 256 CUs, only a kernel boundary is saved)
