@@ -77,7 +77,8 @@ def test_8x8_resblock_tilings_agree(gu):
     y = gu.resblock(sd, "rb", x, None, t, "bf16")
     assert torch.equal(y, _with({"WDM_WSM": "0"}, lambda: gu.resblock(sd, "rb", x, None, t, "bf16")))
     y64 = _with({"WDM_DMA8_BN": "64"}, lambda: gu.resblock(sd, "rb", x, None, t, "bf16"))      # GroupNorm partials in another association
-    assert rel_linf(y, y64) <= 2e-3
+    # a conv input that rounds the other way is ONE bf16 ulp: <= 2^-7 of the largest output, on a small fraction of the outputs
+    assert rel_linf(y, y64) <= 8e-3 and float(((y - y64).abs() > 0).float().mean()) <= 1e-2
 
 
 @pytest.mark.parametrize("C", [512, 256])
@@ -168,3 +169,55 @@ def test_proj_out_fused_into_the_attention_core_gives_the_same_bits(gu):
         y0 = _with({"WDM_ATTN_PROJ": "0"}, lambda: gu.attn(sd, "at", x, "bf16"))
         assert torch.isfinite(y).all() and torch.equal(y, y0), C
         assert rel_linf(y, gu.attn(sd, "at", x, "f32")) <= gu.TOL["bf16"]
+
+
+def test_in_tile_groupnorm_of_the_producing_conv_gives_the_bits_of_the_pass(gu):
+    """gn_group.h: gn_out_tail -- conv1 of an 8x8 ResnetBlock writes act(norm2(h)) itself (two whole images x two whole groups per 128 x 48 tile of
+    conv_dma8_kernel.h) instead of a gn_finalize_apply launch (WDM_GN_TILE=0).  Same reduction (gn_group_stats over the same float4 partials), same
+    elementwise arithmetic (gn_apply_vec): the same bits; odd batches exercise the half-empty last tile."""
+    from wavedm_amd import _lib
+    for cin, cout, B, nin in ((768, 768, 3, False), (512, 768, 2, True), (768, 768, 64, False)):
+        shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+                  "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+        if nin:
+            shapes.update({"nin_shortcut.weight": (cout, cin, 1, 1), "nin_shortcut.bias": (cout,)})
+        sd = gu.blk_sd("rb", shapes)
+        x, t = gu.seeded((B, cin, 8, 8), 5), gu.seeded((B, 512), 6)
+
+        def run():
+            _lib.prof_enable(True)
+            out = gu.resblock(sd, "rb", x, None, t, "bf16")
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+            _lib.prof_enable(False)
+            return out, names
+        y, k1 = run()
+        y0, k0 = _with({"WDM_GN_TILE": "0"}, run)
+        assert torch.isfinite(y).all() and torch.equal(y, y0), (cin, cout, B)
+        n1, n0 = sum("gn_finalize_apply" in k for k in k1), sum("gn_finalize_apply" in k for k in k0)
+        assert (n1, n0) == (1, 2), (k1, k0)                                          # norm2's pass is gone, norm1's (no producer here) stays
+        assert rel_linf(y, gu.resblock(sd, "rb", x, None, t, "f32")) <= gu.TOL["bf16"]
+
+
+def test_in_tile_groupnorm_whole_unet_same_bits_fewer_launches():
+    """The raindrop_wavelet UNet with and without the in-tile GroupNorm: conv2 of the ResnetBlocks in front of the AttnBlocks (16 x 16 maps: one image x
+    128 columns per tile of conv_dma_kernel.h) and of the 8 x 8 ResnetBlocks also writes the consumer's norm.  Bit-identical output, 15 launches fewer."""
+    from test_gpu_unet import build, seeded
+    from wavedm_amd import procedural as P, _lib
+    net = build(P.raindrop_wavelet_config(), "bf16")
+    for B in (3, 64):
+        x = seeded((B, 64, 64, 96), 5).cuda().to(torch.bfloat16).contiguous()
+        ts = torch.tensor([500.0], device="cuda")
+
+        def run():
+            _lib.prof_enable(True)
+            out = net.forward_nhwc(x, ts, torch.empty(B, 3, 64, 64, device="cuda")).clone()
+            n = {}
+            for e in _lib.prof_report():
+                k = e["kernel"].split("|")[0]
+                n[k] = n.get(k, 0) + int(e["launches"])
+            _lib.prof_enable(False)
+            return out, n
+        y, n1 = run()
+        y0, n0 = _with({"WDM_GN_TILE": "0"}, run)
+        assert torch.isfinite(y).all() and torch.equal(y, y0), B
+        assert n0["gn_finalize_apply_kernel"] - n1.get("gn_finalize_apply_kernel", 0) == 15, (n0, n1)

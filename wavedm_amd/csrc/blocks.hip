@@ -69,7 +69,8 @@ int alloc_tens(Ctx& c, int C, int H, int W, Tens* t) {
 void free_tens(Ctx& c, Tens& t) {
     c.ar->free(t.p);
     if (t.stats) c.ar->free(t.stats);
-    t.p = nullptr; t.stats = nullptr; t.gst = nullptr; t.nslab = 0;
+    if (t.nrm) c.ar->free(t.nrm);                        // a normalised copy nobody took
+    t.p = nullptr; t.stats = nullptr; t.gst = nullptr; t.nslab = 0; t.nrm = nullptr; t.nrm_for = nullptr;
 }
 
 static int alloc_f32(Ctx& c, size_t n, float** p) {
@@ -94,7 +95,7 @@ void env_cfg_refresh() {
     c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
     c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->grid_gn = num("WDM_GRID_GN", 1);
     c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
+    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = flag("WDM_GN_TILE", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
     c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
     c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
@@ -131,7 +132,7 @@ int launch_gemm_pair(const ConvArgs& a0, const ConvArgs& b0, int dtype, hipStrea
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
              int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats, const ConvW* shortcut,
-             const Tens* sx0, const Tens* sx1, const NormW* gn_inl, ConvArgs* defer) {
+             const Tens* sx0, const Tens* sx1, const NormW* gn_inl, ConvArgs* defer, const NormW* on, int on_silu) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -177,11 +178,18 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     }
     if (want_stats && !y_ext && w.cout % 8 == 0) {
         // the producing conv also emits the GroupNorm partial statistics of its output (no extra pass over HBM)
-        int nslab = 0;
+        int nslab = 0, yn_ok = 0;
         ConvArgs q = a;
-        q.query_nslab = &nslab;
+        q.query_nslab = &nslab; q.query_yn = &yn_ok;
         WDM_TRY(launch_conv(q, mode, c.dtype, c.s));
         out->nslab = nslab;
+        if (on && yn_ok && env_cfg().gn_tile && on->c == w.cout) {
+            // the kernel this conv runs on holds whole images x whole groups per tile: it also writes act(GroupNorm(out)) for the consumer (gn_group.h)
+            out->nrm = c.ar->alloc((size_t)c.B * Ho * Wo * w.cout * dsize(c.dtype));
+            if (!out->nrm) WDM_FAIL(WDM_ENOMEM, "workspace too small (normalised copy)");
+            out->nrm_for = on->g; out->nrm_silu = on_silu;
+            a.yn = out->nrm; a.on_gamma = on->g; a.on_beta = on->b; a.on_eps = 1e-6f; a.on_silu = on_silu;
+        }
         // group-level partials ride behind the per-channel ones where a consumer can finalise from them (gn_inline.h): group widths 4 / 8 / 16
         const bool want_gst = c.dtype == WDM_BF16 && env_cfg().gn_inline && gn_inline_shape_ok(w.cout, nslab);
         const size_t sb = gn_stats_bytes(c.B, nslab, w.cout);
@@ -245,6 +253,14 @@ static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tm
 // act(gn([x0|x1])) as one dense tensor (silu != 0: with SiLU) -- one launch (k_gn_finalize_apply), or finalize + apply per tensor with WDM_GN_FUSED=0
 static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int silu, Tens* out) {
     const int C = x0.C + (x1 ? x1->C : 0);
+    if (!x1 && x0.nrm && x0.nrm_for == nw.g && x0.nrm_silu == silu) {
+        // the producing conv wrote it already (run_conv: on); the caller owns (and frees) it from here
+        Tens& src = const_cast<Tens&>(x0);
+        *out = Tens();
+        out->p = src.nrm; out->C = C; out->H = x0.H; out->W = x0.W; out->xs = C;
+        src.nrm = nullptr; src.nrm_for = nullptr;
+        return WDM_OK;
+    }
     if (env_cfg().gn_fused && gn_fused_pass_eligible(x0.C, x1 ? x1->C : 0, c.dtype)) {
         float *st0 = nullptr, *st1 = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
         int ns0 = 0, ns1 = 1;
@@ -276,7 +292,7 @@ static bool gn_inline_ok(const Ctx& c, const Tens& x0, const Tens* x1, int cout)
            x0.W % 16 == 0 && cout >= 128;
 }
 
-int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out) {
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n, int next_silu) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
     if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
@@ -286,7 +302,8 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     if (pass) {
         Tens a1;
         WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
-        WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, &w.n2, 1));            // ... and act(norm2(h)) for conv2 where the kernel can (8 x 8 maps: conv_dma8_kernel.h)
         free_tens(c, a1);
     } else if (gn_inline_ok(c, x0, x1, w.cout)) {
         // conv1's GroupNorm finalised in conv1's own prologue from the producer's group partials: no gn_finalize launch (gn_inline.h)
@@ -309,16 +326,16 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     if (pass) {
         Tens a2;
         WDM_TRY(materialize_gn_silu(c, w.n2, t1, nullptr, &a2));
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu));
         free_tens(c, a2);
     } else if (gn_inline_ok(c, t1, nullptr, w.cout)) {
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, &w.n2));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n2));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, &w.n2, nullptr, next_n, next_silu));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n2, nullptr, next_n, next_silu));
     } else {
         WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu));
         c.ar->free(sc2); c.ar->free(sh2);
     }
     free_tens(c, t1);

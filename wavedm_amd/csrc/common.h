@@ -63,6 +63,11 @@ struct Tens {
     float* stats = nullptr;   // GroupNorm partial statistics float4[B][nslab][C] written by the producing conv, or nullptr
     int nslab = 0;
     float* gst = nullptr;     // group-level partials float[B][nslab][32][3] behind them in the same allocation (C = 128 / 256 / 512), or nullptr: gn_inline.h
+    // act(GroupNorm(this tensor)) already written by the producing conv (gn_group.h: gn_out_tail) for the norm whose gamma is nrm_for: materialize_gn
+    // takes it instead of launching gn_finalize_apply
+    void* nrm = nullptr;
+    const float* nrm_for = nullptr;
+    int nrm_silu = 0;
 };
 
 struct Ctx {
@@ -202,6 +207,7 @@ struct EnvCfg {
     int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)
     int gemm8 = 0;        // WDM_GEMM8=1: 1x1 convs on 8 x 8 maps (middle AttnBlock) on the LDS-DMA GEMM kernel, four images per tile -- measured 25.8 vs 22.4 us
                           // (768->768) and 23.0 vs 23.9 (768->1536): 96 / 192 workgroups of a 12-step K loop are latency, not staging
+    int gn_tile = 1;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h)
     int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
     int up4_gn = 1;       // WDM_UP4_GN=2|4|8: N-tile groups per XCD of the 8 x 8 sub-pixel upsample kernel
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
@@ -220,9 +226,11 @@ int launch_gemm_pair(const ConvArgs& a, const ConvArgs& b, int dtype, hipStream_
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
              bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr,
-             ConvArgs* defer = nullptr);      // defer: fill *defer instead of launching (launch_gemm_pair)
+             ConvArgs* defer = nullptr,       // defer: fill *defer instead of launching (launch_gemm_pair)
+             const NormW* on = nullptr, int on_silu = 0);      // on: the consumer's norm -- out->nrm = act(GroupNorm(out)) from the conv itself where its kernel can
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
-int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out);
+// next_n: the norm of the consumer of *out when that consumer normalises in a pass of its own (an AttnBlock, an 8 x 8 ResnetBlock): conv2 writes it (run_conv: on)
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n = nullptr, int next_silu = 0);
 int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);
 int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);
 void free_tens(Ctx& c, Tens& t);

@@ -11,6 +11,7 @@
 // vmcnt waits, one raw barrier per sub-stage, 24 MFMAs per wave and sub-stage.  LDS 76 KB.
 #pragma once
 #include "conv_kernel.h"
+#include "gn_group.h"
 
 #ifndef WDM_D8ABL
 #define WDM_D8ABL 0         // tools/dma8_ablate.hip: 2 = no MFMAs, 16 (with 2) = no fragment reads either, 4 = no halo DMA, 8 = no weight DMA
@@ -21,29 +22,35 @@ namespace wdm {
 // BN_ = 64: waves 2 (M) x 2 (N), 64 x 32 wave tiles.  BN_ = 48: waves 4 (M) x 1 (N), 32 x 48 wave tiles -- for Cout = 768 at batch 64 the 64-wide
 // tile gives 384 workgroups on 512 slots (half the CUs run two, half one: scripts/dma8_fill_probe.py, 55.8 us where a full 512 takes 62), the
 // 48-wide one exactly 512 of 3/4 the size.  The weight sub-stage keeps its 12 KB image (rows >= 3 * 48 are never fetched).
-template <int BN_>
+template <int BN_, int NI_ = 2>
 struct ConvDma8Cfg {
     static_assert(BN_ == 64 || BN_ == 48, "N tile");
-    static constexpr int TH = 8, TW = 8, NI = 2;
-    static constexpr int WAVES_M = BN_ == 64 ? 2 : 4, WAVES_N = BN_ == 64 ? 2 : 1, WM = BN_ == 64 ? 4 : 2, WN = BN_ == 64 ? 2 : 3;
+    static_assert(NI_ == 2 || NI_ == 4, "images per tile");
+    // NI_ = 4 (round 3): four images per tile on EIGHT waves of the same wave tiles -- one workgroup per CU instead of two, so the CU fetches a weight
+    // sub-stage once for 256 rows instead of twice for 128 each: 53 KB of DMA per slab and CU instead of 80 KB (the kernel is DMA-bound: with the MFMAs
+    // and fragment reads compiled out it still takes 40 of its 49 us, tools/dma8_ablate.hip).  Same wave tiles, same K order, same statistics slabs:
+    // the same bits as NI_ = 2.
+    static constexpr int TH = 8, TW = 8, NI = NI_;
+    static constexpr int WAVES_M = (BN_ == 64 ? 2 : 4) * (NI / 2), WAVES_N = BN_ == 64 ? 2 : 1, WM = BN_ == 64 ? 4 : 2, WN = BN_ == 64 ? 2 : 3;
     static constexpr int NJ = BN_ == 64 ? 0 : 1;                // epilogue: 16-column fragments per pass (0 = default pair)
-    static constexpr int NWAVES = 4, NTHREADS = 256, BN = BN_, BK = 32;
+    static constexpr int NWAVES = WAVES_M * WAVES_N, NTHREADS = 64 * NWAVES, BN = BN_, BK = 32;
     static constexpr int PH = 10, PW = 10, RS = 16;
     static constexpr int PLANE_IMG = PH * RS;                   // 160 row slots per image
-    static constexpr int A_ROWS = NI * PLANE_IMG;               // 320
-    static constexpr int A_CPW = 5, B_CPW = 3;                  // 1 KB DMA pieces per wave: 20 halo pieces, 12 per weight sub-stage
-    static constexpr int A_BYTES = 20 * 1024;
-    static constexpr int B_SUB = 3 * 64 * 64;                   // 12 KB
+    static constexpr int A_ROWS = NI * PLANE_IMG;               // 320 | 640
+    static constexpr int A_CPW = 5, B_CPW = NWAVES == 4 ? 3 : 2;    // 1 KB DMA pieces per wave: 10 NI halo pieces; 12 | 16 per weight sub-stage (9 | 12 hold rows)
+    static constexpr int A_BYTES = 10 * NI * 1024;
+    static constexpr int B_SUB = NWAVES * B_CPW * 1024;         // 12 | 16 KB
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 76 KB: two workgroups per CU
+    static constexpr int LDS_BYTES = B_OFF + 3 * B_SUB;         // 76 KB: two workgroups per CU | 128 KB: one
     static constexpr int EPI_BYTES = NWAVES * 16 * WM * (16 * 2 + 4) * 4;
-    static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 80 * 1024, "LDS");
-    static_assert(WAVES_M * WM * 16 == NI * TH * TW && WAVES_N * WN * 16 == BN, "tile");
+    static constexpr int G_ROWS = NI * 64, G_A = G_ROWS * 128, G_STAGE = G_A + 64 * 128, GB_CPW = 8 / NWAVES;     // the shortcut's GEMM stages
+    static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= (NI == 2 ? 80 : 160) * 1024 && 3 * G_STAGE <= LDS_BYTES, "LDS");
+    static_assert(WAVES_M * WM * 16 == NI * TH * TW && WAVES_N * WN * 16 == BN && A_CPW * NWAVES * 16 == A_ROWS && 3 * BN <= B_SUB / 64, "tile");
 };
 
-template <int BN_>
-__global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
-    using C = ConvDma8Cfg<BN_>;
+template <int BN_, int NI_ = 2>
+__global__ __launch_bounds__((ConvDma8Cfg<BN_, NI_>::NTHREADS), 2) void conv_dma8_kernel(const ConvArgs a) {
+    using C = ConvDma8Cfg<BN_, NI_>;
     using T = __bf16;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, NI = C::NI, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
     auto mfma_dx = [&](int s, int dx) __attribute__((always_inline)) {
         if ((WDM_D8ABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
-        const char* pb = smem + dx * C::B_SUB;
+        const char* pb = smem + dx * C::B_SUB;      // + C::B_OFF: in b_addr
         uint4 ae[WM + 1], ao[WM];
 #pragma unroll
         for (int i = 0; i < WM; ++i) { ae[i] = *(const uint4*)(pa + a_addr[i][dx]); ao[i] = *(const uint4*)(pa + a_addr[i][dx] + RS * 64); }
@@ -181,13 +188,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
     // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1), as in
     // conv_dma_kernel.h: a plain GEMM over the tile's 128 pixels, 64 channels per K step, three 24 KB stages over the idle operand buffers
     if (a.sx0 != nullptr) {
-        constexpr int G_A = 128 * 128, G_STAGE = G_A + 64 * 128;
-        static_assert(3 * G_STAGE <= C::LDS_BYTES, "shortcut ring");
+        constexpr int G_A = C::G_A, G_STAGE = C::G_STAGE, GBC = C::GB_CPW;
         const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
-        unsigned g_a0[4], g_a1[4], g_b[2];
+        unsigned g_a0[4], g_a1[4], g_b[GBC];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (wave * 4 + i) * 8 + (lane >> 3);          // 0..127: image row / 64, pixel row % 64
+            const int row = (wave * 4 + i) * 8 + (lane >> 3);          // 0..64 NI - 1: image row / 64, pixel row % 64
             const int u = (lane & 7) ^ ((row >> 1) & 7);
             const bool ok = img0 + row / 64 < a.B;
             const unsigned gp = (unsigned)((img0 + row / 64) * 64 + row % 64);
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
             g_a1[i] = ok ? gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16) : OOB;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 8 + (lane >> 3);          // 0..63
+        for (int i = 0; i < GBC; ++i) {
+            const int row = (wave * GBC + i) * 8 + (lane >> 3);        // 0..63
             const int u = (lane & 7) ^ ((row >> 1) & 7);
             const int n = n0 + row;
             g_b[i] = (row < BN && n < a.sw_rows) ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
                 for (int i = 0; i < 4; ++i) dma16(q_s1, base + (wave * 4 + i) * 1024, g_a1[i], (c - a.sC0) * 2);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma16(q_sw, base + G_A + (wave * 2 + i) * 1024, g_b[i], c * 2);
+            for (int i = 0; i < GBC; ++i) dma16(q_sw, base + G_A + (wave * GBC + i) * 1024, g_b[i], c * 2);
         };
         const int sw7 = (lane >> 1) & 7;
         int a2[2], b2[2];
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
         if (nk > 1) issue2(1, 1);
         int buf = 0;
         for (int k = 0; k < nk; ++k) {
-            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + GBC) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2);
@@ -249,7 +255,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma8_kernel(const ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    conv_epilogue<T, TH, TW, WM, WN, C::NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0);
+    // the tile is NI whole images x BN columns: the consumer's act(GroupNorm(y)) from here when it asked for it (gn_group.h; the epilogue keeps its tiles)
+    using G = GnTailGeom<TH, TW, WM, WN, C::NJ, C::WAVES_N>;
+    static_assert(G::total_bytes(C::NWAVES, NI, BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
+    float4* keep_tab = a.yn != nullptr ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
+    conv_epilogue<T, TH, TW, WM, WN, C::NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0, 0, EpiNoHook(), true, keep_tab, BN);
+    if (a.yn != nullptr) gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, BN>(a, img0, NI, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(NI, BN)), tid);
 }
 
 }  // namespace wdm

@@ -93,6 +93,14 @@ struct ConvArgs {
     const float* gn_gamma; // [Cin]
     const float* gn_beta;  // [Cin]
     float gn_eps;
+    // producer side, in-tile GroupNorm of the OUTPUT (gn_group.h: gn_out_tail): with stats set, kernels whose tile holds whole images x whole groups also
+    // write yn = act(GroupNorm(y)) -- the normalised (+ SiLU) copy the consumer would otherwise get from a gn_finalize_apply launch
+    void* yn;              // dense [B][Hout][Wout][Cout] model dtype, or nullptr
+    const float* on_gamma; // [Cout]
+    const float* on_beta;  // [Cout]
+    float on_eps;
+    int on_silu;
+    int* query_yn;         // host only: when set, the launcher stores 1 if the kernel it would pick for this shape can write yn (else 0) and does not launch
     int no_direct;         // 1: statistics through the LDS column pass even where the epilogue could take them from the accumulators (WDM_EPI_DIRECT=0)
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
@@ -320,7 +328,10 @@ struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
 template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_pass, char* smem, bool active, int wave, int lane, int wave_m,
                                                 int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
-                                                bool entry_barrier = true, bool pre_applied = false) {
+                                                bool entry_barrier = true, bool pre_applied = false, float4* keep_tab = nullptr, int keep_bn = 0) {
+    // keep_tab (LDS; tiles of whole images only): the in-tile GroupNorm of the output (gn_group.h: gn_out_tail) follows -- every pass gets its own LDS tile, so
+    // that the final values (as stored: the statistics pass writes them back) are all still there afterwards, and the (pivot, s1, s2, n) of every
+    // (image, slab, column) of the tile also goes into keep_tab[(image * slabs + slab) * keep_bn + column]
     // pre_applied: the tile already holds the FINAL values (alpha * acc + bias + temb, no residual) and the statistics are written (conv_epilogue's
     // direct path): rows are only rounded and stored
     constexpr int VEC = TI<T>::VEC;
@@ -331,7 +342,8 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
     constexpr int EROWS = 16 * WM;
     constexpr int LPR = ECOLS / 8;                    // lanes per row
     constexpr int RPI = 64 / LPR;                     // rows per iteration
-    float* ep = (float*)smem + wave * (EROWS * ESTR);
+    float* const ep0 = (float*)smem + wave * (EROWS * ESTR);
+    const int keep_stride = keep_tab != nullptr ? (int)(blockDim.x >> 6) * (EROWS * ESTR) : 0;      // floats between the tiles of consecutive passes
     const bool vec_ok = (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
     // output / residual through raw buffer descriptors (extents checked on the host: conv_dispatch.inc)
     const long long out_rows = a.up4 ? (long long)a.B * 4 * a.Hout * a.Wout : (a.m_valid ? (long long)a.m_valid : (long long)a.B * a.Hout * a.Wout);
@@ -370,6 +382,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
     constexpr bool TEMB_IN_ADD = (TH * TW) % EROWS == 0;
 #pragma unroll
     for (int jp = 0; jp < WN; jp += NJ) {
+        float* const ep = ep0 + (jp / NJ) * keep_stride;
         // The fp32 tile is private to the wave, and the LDS executes one wave's instructions in order: only the hand-over from the
         // main loop (other waves may still read the operand images this tile overlays) needs the workgroup barrier.
         if (jp == 0) { WDM_ETS(1); if (entry_barrier) __syncthreads(); WDM_ETS(2); }
@@ -541,6 +554,8 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 const int nn = ncol0 + col;
                 if ((r0 % SROWS) == 0 && nn < a.Cout && img_g < a.B)
                     ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, (float)SROWS);
+                if (keep_tab != nullptr && (r0 % SROWS) == 0 && nn < a.Cout)
+                    keep_tab[((m0 / (TH * TW)) * SPT + (m0 % (TH * TW)) / SROWS) * keep_bn + (nn - n0)] = make_float4(K, s1, s2, (float)SROWS);
                 if (a.gst != nullptr) {
                     // group-level partials: the gs = Cout / 32 channels of a group are gs consecutive lanes (gs divides the pass's columns: host check);
                     // re-centred on the group's first channel and summed by a fixed xor tree, explicit fma (every instantiation rounds alike)
@@ -594,7 +609,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
 template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
                                               int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
-                                              bool entry_barrier = true) {
+                                              bool entry_barrier = true, float4* keep_tab = nullptr, int keep_bn = 0) {
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
     constexpr int ESTR = 16 * NJ + 4;
@@ -612,7 +627,7 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
     constexpr int SROWS_ = conv_stat_rows(TH, TW, EROWS_);
     bool direct = false;
     if constexpr (ONE_IMG_ && SROWS_ % 16 == 0 && EROWS_ % SROWS_ == 0) {
-        direct = active && !a.no_direct && a.stats != nullptr && a.res == nullptr && a.m_valid == 0 && (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
+        direct = active && !a.no_direct && keep_tab == nullptr && a.stats != nullptr && a.res == nullptr && a.m_valid == 0 && (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
         if (direct) {
             constexpr int FPS = SROWS_ / 16, NSL = EROWS_ / SROWS_, SPT = (TH * TW) / SROWS_;
             const int img_w = img0 + (wave_m * EROWS_) / (TH * TW);
@@ -700,7 +715,7 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
                 *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
     conv_epilogue_w<T, TH, TW, WM, WN, NJ_, decltype(write_pass)&, Hook, CANON>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, entry_barrier,
-                                                                                direct);
+                                                                                direct, keep_tab, keep_bn);
     WDM_ETS(5);
 #ifdef WDM_EPI_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

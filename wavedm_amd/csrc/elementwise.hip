@@ -2,6 +2,7 @@
 // scatter-mean + DDIM update, layout conversion, GroupNorm statistics, attention softmax, the timestep-embedding
 // MLP, and weight packing.  All deterministic (no atomics): every reduction has a fixed order.
 #include "common.h"
+#include "gn_group.h"
 
 namespace wdm {
 
@@ -332,73 +333,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-// mean / rstd of group g of image b from the partial statistics of [x0 | x1]: the work of ONE wave (all 64 lanes take part; every lane returns the result),
-// in two steps so that a wave that owns several groups can have all their loads in flight at once.  Shared by gn_finalize_kernel and
-// gn_finalize_apply_kernel so that both produce the same bits: the accumulation order per lane (ascending item index) and the shuffle tree are fixed.
-struct GnGroupLoad { float kgf; float4 v0[4]; int items, items0, n0c, cg0; };
-__device__ __forceinline__ float4 gn_load_item(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C1, int b,
-                                               const GnGroupLoad& L, int it) {
-    // slab counts are powers of two for every map of the model: shifts instead of ~35-instruction run-time divisions (four per item -- they were most of
-    // this kernel's instruction count)
-    auto divmod = [](int x, int d, int& q, int& r) __attribute__((always_inline)) {
-        if ((d & (d - 1)) == 0) { const int sh = __builtin_ctz(d); q = x >> sh; r = x & (d - 1); } else { q = x / d; r = x - q * d; }
-    };
-    int ci, sl;
-    if (it < L.items0) { divmod(it, nslab0, ci, sl); return st0[((long long)b * nslab0 + sl) * C0 + L.cg0 + ci]; }
-    divmod(it - L.items0, nslab1, ci, sl);
-    return st1[((long long)b * nslab1 + sl) * C1 + (L.cg0 + L.n0c + ci - C0)];
-}
-__device__ __forceinline__ void gn_group_load(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int g, int b, int lane,
-                                              GnGroupLoad& L) {
-    const int gw = C / 32, C1 = C - C0;
-    L.cg0 = g * gw;
-    // ONE memory round trip: the group's pivot (first channel, slab 0) and the first batch of partials are requested before anything is used
-    const float4* kp = (L.cg0 < C0) ? &st0[((long long)b * nslab0) * C0 + L.cg0] : &st1[((long long)b * nslab1) * C1 + (L.cg0 - C0)];
-    L.kgf = kp->x;
-    // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
-    L.n0c = max(0, min(C0 - L.cg0, gw));        // channels of this group that live in tensor 0
-    L.items0 = L.n0c * nslab0;
-    L.items = L.items0 + (gw - L.n0c) * nslab1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) L.v0[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, lane + 64 * u);
-}
-__device__ __forceinline__ void gn_group_reduce(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
-                                                int b, int lane, const GnGroupLoad& L, float& mean, float& rstd) {
-    const int gw = C / 32, C1 = C - C0;
-    double S1 = 0.0, S2 = 0.0;
-    const double kg = (double)L.kgf;
-    auto accumulate = [&](const float4& v) __attribute__((always_inline)) {
-        const double n = (double)v.w, d = (double)v.x - kg, a1 = (double)v.y, a2 = (double)v.z;
-        S1 += a1 + n * d;
-        S2 += a2 + 2.0 * d * a1 + n * d * d;
-    };
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) accumulate(L.v0[u]);
-    for (int it0 = lane + 256; it0 < L.items; it0 += 256) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) v[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, it0 + 64 * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) accumulate(v[u]);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        S1 += __shfl_xor(S1, o);
-        S2 += __shfl_xor(S2, o);
-    }
-    const double N = (double)gw * (double)HW;
-    const double m = S1 / N;
-    double var = S2 / N - m * m;
-    if (var < 0.0) var = 0.0;
-    mean = (float)(kg + m);
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
-}
-__device__ __forceinline__ void gn_group_stats(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
-                                               int g, int b, int lane, float& mean, float& rstd) {
-    GnGroupLoad L;
-    gn_group_load(st0, nslab0, C0, st1, nslab1, C, g, b, lane, L);
-    gn_group_reduce(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L, mean, rstd);
-}
+// gn_group_load / gn_group_reduce / gn_group_stats, gn_scale_shift, gn_apply_vec: gn_group.h (shared with the conv epilogues' in-tile GroupNorm)
 
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1,
                                                          int C, int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -415,9 +350,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float4* __restric
     for (int ci = lane; ci < gw; ci += 64) {
         const int c = cg0 + ci;
         const float gm = ci < 64 ? gam0 : gamma[c], bt = ci < 64 ? bet0 : beta[c];
-        const float sc = rstd * gm;
+        float sc, sh;
+        gn_scale_shift(mean, rstd, gm, bt, sc, sh);
         scale[(long long)b * C + c] = sc * premul;
-        shift[(long long)b * C + c] = (bt - mean * sc) * premul;
+        shift[(long long)b * C + c] = sh * premul;
     }
 }
 
@@ -440,47 +376,32 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float4* __
     const int gw = C / 32;
     const int cw = GPW * gw, c_first = q * cw;        // the workgroup's channel range [c_first, c_first + cw)
     const int cols = cw / VEC;                        // 16-byte vectors per pixel in that range (C0, gw * GPW multiples of VEC: host check)
-    const long long nv = (long long)HW * cols;
-    auto x_load = [&](long long id) __attribute__((always_inline)) -> uint4 {
-        const int col = (int)(id % cols);
-        const long long bp = (long long)b * HW + id / cols;
-        const int c = c_first + col * VEC;
-        return c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
-    };
+    // thread = (pixel phase, vector column), fixed for the whole loop: no division per vector (the 64-bit `id % cols`, `id / cols` of the first form were
+    // ~200 instructions per vector, more than the arithmetic); 256 % cols threads idle (cols = 12: 4 of 256)
+    const int ppi = blockDim.x / cols;                // pixels per iteration
+    const int p0 = threadIdx.x / cols, col = threadIdx.x - p0 * cols;
+    const bool live = p0 < ppi;
+    const int c = c_first + col * VEC, cl = col * VEC;
+    const T* xsrc = c < C0 ? x0 + ((long long)b * HW) * xs0 + c : x1 + ((long long)b * HW) * xs1 + (c - C0);
+    const int xs = c < C0 ? xs0 : xs1;
+    T* ydst = y + ((long long)b * HW) * C + c;
     constexpr int NPF = 4;
     uint4 xr[NPF];
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) xr[k] = x_load(id); }
+    for (int k = 0; k < NPF; ++k) { const int p = p0 + k * ppi; if (live && p < HW) xr[k] = *(const uint4*)(xsrc + (long long)p * xs); }
     {
         const int g = q * GPW + wave;
         float gam = 0.f, bet = 0.f;
         if (lane < gw) { gam = gamma[g * gw + lane]; bet = beta[g * gw + lane]; }
         float mean, rstd;
         gn_group_stats(st0, nslab0, C0, st1, nslab1, C, HW, eps, g, b, lane, mean, rstd);
-        if (lane < gw) {
-            const float sc = rstd * gam;
-            tab[0][wave * gw + lane] = sc;
-            tab[1][wave * gw + lane] = bet - mean * sc;
-        }
+        if (lane < gw) gn_scale_shift(mean, rstd, gam, bet, tab[0][wave * gw + lane], tab[1][wave * gw + lane]);
     }
     __syncthreads();
-    auto apply = [&](long long id, const uint4& u) __attribute__((always_inline)) {
-        const int col = (int)(id % cols);
-        const long long bp = (long long)b * HW + id / cols;
-        const int cl = col * VEC;
-        float f[VEC];
-        TI<T>::unpack(u, f);
+    if (!live) return;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) f[e] = f[e] * tab[0][cl + e] + tab[1][cl + e];
-        if (silu) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
-        }
-        *(uint4*)(y + bp * C + c_first + cl) = TI<T>::pack(f);
-    };
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) { const long long id = threadIdx.x + (long long)k * blockDim.x; if (id < nv) apply(id, xr[k]); }
-    for (long long id = threadIdx.x + (long long)NPF * blockDim.x; id < nv; id += blockDim.x) apply(id, x_load(id));
+    for (int k = 0; k < NPF; ++k) { const int p = p0 + k * ppi; if (p < HW) *(uint4*)(ydst + (long long)p * C) = gn_apply_vec<T>(xr[k], &tab[0][cl], &tab[1][cl], silu); }
+    for (int p = p0 + NPF * ppi; p < HW; p += ppi) *(uint4*)(ydst + (long long)p * C) = gn_apply_vec<T>(*(const uint4*)(xsrc + (long long)p * xs), &tab[0][cl], &tab[1][cl], silu);
 }
 
 int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s) {
@@ -501,8 +422,15 @@ int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const flo
     if (C != nw.c || C % 32) WDM_FAIL(WDM_EINVAL, "groupnorm: %d channels vs %d weights (must be a multiple of 32)", C, nw.c);
     // for_silu_conv: the consumer is a conv with the fused GN+SiLU prologue, which wants scale/shift pre-multiplied by -log2(e)
     const float premul = for_silu_conv ? -1.4426950408889634f : 1.0f;
+    const bool prof = prof_enabled();
+    if (prof) {
+        char name[64];
+        snprintf(name, sizeof(name), "gn_finalize_kernel|%d px C=%d", HW, C);
+        prof_begin(s, name, 0.0, 16.0 * B * (nslab0 * (double)C0 + (st1 ? nslab1 * (double)C1 : 0.0)) + 8.0 * B * C);
+    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW,
                        nw.g, nw.b, eps, premul, scale, shift, mean_rstd);
+    if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -519,12 +447,20 @@ int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0,
     const int C0 = x0.C, C1 = x1 ? x1->C : 0, C = C0 + C1, HW = x0.H * x0.W;
     if (C != nw.c || !gn_fused_pass_eligible(C0, C1, dtype)) WDM_FAIL(WDM_EINVAL, "groupnorm: %d + %d channels vs %d weights unsupported by the fused pass", C0, C1, nw.c);
     const dim3 grid(8, B);
+    const bool prof = prof_enabled();
+    if (prof) {
+        const double es = dtype == WDM_BF16 ? 2.0 : 4.0;
+        char name[64];
+        snprintf(name, sizeof(name), "gn_finalize_apply_kernel|%dx%d C=%d%s", x0.H, x0.W, C, silu ? " silu" : "");
+        prof_begin(s, name, 0.0, 2.0 * B * HW * C * es + 16.0 * B * (nslab0 * (double)C0 + (st1 ? nslab1 * (double)C1 : 0.0)));
+    }
     if (dtype == WDM_BF16)
         hipLaunchKernelGGL(gn_finalize_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
                            nw.b, eps, (const __bf16*)x0.p, x0.xs, (const __bf16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (__bf16*)y, silu);
     else
         hipLaunchKernelGGL(gn_finalize_apply_kernel<float>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
                            nw.b, eps, (const float*)x0.p, x0.xs, (const float*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (float*)y, silu);
+    if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -543,17 +479,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         const long long b = bp / HW;
         const int c = col * VEC;
         const uint4 u = *(const uint4*)(x + bp * xs + c);
-        float f[VEC];
-        TI<T>::unpack(u, f);
-        const float* ps = scale + b * sc_ld + c;
-        const float* pf = shift + b * sc_ld + c;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) f[e] = f[e] * ps[e] + pf[e];
-        if (silu) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
-        }
-        *(uint4*)(y + bp * ys + c) = TI<T>::pack(f);
+        *(uint4*)(y + bp * ys + c) = gn_apply_vec<T>(u, scale + b * sc_ld + c, shift + b * sc_ld + c, silu);       // the arithmetic of the fused pass (gn_group.h)
     }
 }
 int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int sc_ld, void* y, int y_stride, int y_choff, int silu, int dtype,

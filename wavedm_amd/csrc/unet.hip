@@ -273,7 +273,16 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
     for (int l = 0; l < nres; ++l) {
         for (int b = 0; b < nrb; ++b) {
             Tens o;
-            WDM_TRY(run_resblock(c, rw(down_res[l][b], temb_all, n_t), hs.back(), nullptr, &o));
+            // the consumer of the block's output, when it normalises in a pass of its own (an AttnBlock; the next ResnetBlock on the <= 8 x 8 maps): the block's
+            // conv2 writes that norm too where its kernel holds whole images x groups per tile (run_conv: on) -- no gn_finalize_apply launch then
+            NormW nn; int nn_silu = 0; bool have_nn = false;
+            const int hw_l = (R >> l) * (R >> l);
+            if (!down_attn[l].empty()) { nn = aw(down_attn[l][b]).n; have_nn = true; }
+            else if (hw_l <= env_cfg().gn_pass_hw) {
+                if (b + 1 < nrb) { nn = rw(down_res[l][b + 1], temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
+                else if (l == nres - 1) { nn = rw(mid1, temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
+            }
+            WDM_TRY(run_resblock(c, rw(down_res[l][b], temb_all, n_t), hs.back(), nullptr, &o, have_nn ? &nn : nullptr, nn_silu));
             if (!down_attn[l].empty()) {
                 Tens o2;
                 WDM_TRY(run_attn(c, aw(down_attn[l][b]), o, &o2));
@@ -290,7 +299,8 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
     }
     // ---- middle (input stays on the skip stack)
     Tens m1, m2;
-    WDM_TRY(run_resblock(c, rw(mid1, temb_all, n_t), hs.back(), nullptr, &m1));
+    const NormW mid_n = aw(mid_attn).n;
+    WDM_TRY(run_resblock(c, rw(mid1, temb_all, n_t), hs.back(), nullptr, &m1, &mid_n, 0));
     WDM_TRY(run_attn(c, aw(mid_attn), m1, &m2));
     free_tens(c, m1);
     WDM_TRY(run_resblock(c, rw(mid2, temb_all, n_t), m2, nullptr, &h));
@@ -301,7 +311,9 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
             Tens skip = hs.back();
             hs.pop_back();
             Tens o;
-            WDM_TRY(run_resblock(c, rw(up_res[l][b], temb_all, n_t), h, &skip, &o));
+            NormW nn;
+            if (!up_attn[l].empty()) nn = aw(up_attn[l][b]).n;
+            WDM_TRY(run_resblock(c, rw(up_res[l][b], temb_all, n_t), h, &skip, &o, up_attn[l].empty() ? nullptr : &nn, 0));
             free_tens(c, h);
             free_tens(c, skip);
             h = o;
