@@ -221,3 +221,36 @@ def test_in_tile_groupnorm_whole_unet_same_bits_fewer_launches():
         y0, n0 = _with({"WDM_GN_TILE": "0"}, run)
         assert torch.isfinite(y).all() and torch.equal(y, y0), B
         assert n0["gn_finalize_apply_kernel"] - n1.get("gn_finalize_apply_kernel", 0) == 15, (n0, n1)
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 128, 5, 64), (256, 256, 3, 32), (128, 128, 2, 32), (96, 192, 2, 32), (512, 512, 2, 64)])
+def test_downsample_on_the_lds_dma_kernel(gu, cin, cout, B, H):
+    """conv_s2_kernel.h (the stride-2 conv as four stride-1 convs over the input's phases: 2x2 + 1x2 + 2x1 + 1x1 taps) against torch and against the
+    register-staged kernel (WDM_S2_DMA=0): another K order, the same bf16 bound; both N tiles (64 / 128 columns); zero padding at the right / bottom
+    edge only; ragged batches."""
+    from wavedm_amd import _lib
+    w = gu.seeded((cout, cin, 3, 3), 41) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 42) * 0.1
+    x = gu.seeded((B, cin, H, H), 43)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+
+    def run():
+        _lib.prof_enable(True)
+        out = gu.conv(w, b, 1, x, "bf16")
+        names = [e["kernel"].split("|")[0] for e in _lib.prof_report()]
+        _lib.prof_enable(False)
+        return out, names
+    y, k = run()
+    assert any(n.startswith("convs2_") for n in k), k
+    assert rel_linf(y, ref) <= gu.TOL["bf16"]
+    y0, k0 = _with({"WDM_S2_DMA": "0"}, run)
+    assert any(n.startswith("conv_3x3s2") for n in k0) and rel_linf(y, y0) <= gu.TOL["bf16"]
+    if cout % 128 == 0:
+        (y2, k2), (y3, k3) = _with({"WDM_S2_DMA": "2"}, run), _with({"WDM_S2_DMA": "3"}, run)
+        assert any("bn128" in n for n in k2) and any("bn64" in n for n in k3)
+        assert torch.equal(y2, y) and torch.equal(y3, y)                                  # the two N tiles: the same K order per output
+    assert torch.equal(y, run()[0])
+    # an edge the padding must not leak across: the last input row / column is read by tap rows / columns 0 and 1 only
+    xz = x.clone(); xz[:, :, -1, :] = 0; xz[:, :, :, -1] = 0
+    refz = torch.nn.functional.conv2d(torch.nn.functional.pad(xz, (0, 1, 0, 1)), w, b, stride=2)
+    assert rel_linf(gu.conv(w, b, 1, xz, "bf16"), refz) <= gu.TOL["bf16"]

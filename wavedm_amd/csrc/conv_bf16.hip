@@ -8,4 +8,5 @@
 #include "conv_dmap_kernel.h"
 #include "conv_up4_kernel.h"
 #include "conv_dma8_kernel.h"
+#include "conv_s2_kernel.h"
 #include "conv_dispatch.inc"
