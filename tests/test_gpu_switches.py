@@ -254,3 +254,33 @@ def test_downsample_on_the_lds_dma_kernel(gu, cin, cout, B, H):
     xz = x.clone(); xz[:, :, -1, :] = 0; xz[:, :, :, -1] = 0
     refz = torch.nn.functional.conv2d(torch.nn.functional.pad(xz, (0, 1, 0, 1)), w, b, stride=2)
     assert rel_linf(gu.conv(w, b, 1, xz, "bf16"), refz) <= gu.TOL["bf16"]
+
+
+@pytest.mark.parametrize("cin,cout,B,H,cat", [(128, 128, 3, 32, 0), (256, 128, 2, 64, 128), (512, 512, 2, 16, 0), (160, 224, 2, 16, 64)])
+def test_f32x3_resblock_on_the_lds_dma_kernel(gu, cin, cout, B, H, cat):
+    """conv_dmax3_kernel.h (f32x3 mode: hi / lo split once per staged element, in LDS) against the register-staged f32x3 kernel (WDM_X3_DMA=0) and the exact
+    fp32 path: a ResnetBlock with the GroupNorm prologue, temb, residual / 1x1 shortcut, optionally a concat input; Cout not a multiple of the N tile."""
+    from wavedm_amd import _lib
+    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    if cin != cout:
+        shapes.update({"nin_shortcut.weight": (cout, cin, 1, 1), "nin_shortcut.bias": (cout,)})
+    sd = gu.blk_sd("rb", shapes)
+    x = gu.seeded((B, cin, H, H), 5)
+    x0, x1 = (x[:, :cin - cat].contiguous(), x[:, cin - cat:].contiguous()) if cat else (x, None)
+    t = gu.seeded((B, 512), 6)
+
+    def run():
+        _lib.prof_enable(True)
+        out = gu.resblock(sd, "rb", x0, x1, t, "f32x3")
+        names = [e["kernel"].split("|")[0] for e in _lib.prof_report()]
+        _lib.prof_enable(False)
+        return out, names
+    y, k = run()
+    y0, k0 = _with({"WDM_X3_DMA": "0"}, run)
+    assert any(n.startswith("convdmax3") for n in k) and not any(n.startswith("convdmax3") for n in k0), (k, k0)
+    ref = gu.resblock(sd, "rb", x0, x1, t, "f32")
+    e, e0 = rel_linf(y, ref), rel_linf(y0, ref)
+    print(f"f32x3 resblock {cin}->{cout} @{H}: dma {e:.2e}  register-staged {e0:.2e}")
+    assert e <= 2e-5 and e0 <= 2e-5 and rel_linf(y, y0) <= 2e-5
+    assert torch.equal(y, run()[0])

@@ -2,4 +2,6 @@
 #define WDM_PAIR_NAME launch_gemm_pair_f32x3
 #define WDM_LAUNCH_NAME launch_conv_f32x3
 #define WDM_DTYPE_NAME "f32x3"
+#define WDM_HAS_DMAX3 1
+#include "conv_dmax3_kernel.h"
 #include "conv_dispatch.inc"
