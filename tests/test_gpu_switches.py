@@ -284,3 +284,4 @@ def test_f32x3_resblock_on_the_lds_dma_kernel(gu, cin, cout, B, H, cat):
     print(f"f32x3 resblock {cin}->{cout} @{H}: dma {e:.2e}  register-staged {e0:.2e}")
     assert e <= 2e-5 and e0 <= 2e-5 and rel_linf(y, y0) <= 2e-5
     assert torch.equal(y, run()[0])
+    assert torch.equal(y, _with({"WDM_WSM": "0"}, run)[0])                            # weights split in the kernel instead of the pre-split copy: same bits

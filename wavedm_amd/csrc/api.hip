@@ -27,7 +27,7 @@ int pack_conv_w(Scratch& sc, const float* w, const float* b, int cin, int cout, 
     if (conv_sm_eligible(dtype, k, cin)) {              // same selection as the UNet executor: the slab-major copy next to the plain matrix
         char* sm;
         WDM_TRY(sc.get<char>(conv_packed_bytes(cin, cout, k, dtype), &sm));
-        WDM_TRY(k_pack_conv_sm(w, cout, cin, sm, out->rows_pad, s));
+        WDM_TRY(k_pack_conv_sm(w, cout, cin, sm, out->rows_pad, s, dtype));
         out->w_sm = sm;
     }
     return WDM_OK;

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(512, 2) void conv_dmax3_kernel(const ConvArgs a) {
         }
     };
     // hi / lo split, in place, of the weight units this lane fetched into ring slot `slot` (rows past the matrix are zeros)
+    const bool wsplit = a.w_split == 0;              // else the weights arrive split (k_pack_conv_sm: the model's packed copy)
     auto split_b = [&](int slot) __attribute__((always_inline)) {
+        if (!wsplit) return;
         char* base = smem + C::B_OFF + slot * C::B_SUB + lane * 16;
 #pragma unroll
         for (int i = 0; i < BCP; ++i) {

@@ -64,6 +64,7 @@ struct ConvArgs {
     const void* w_sm;      // slab-major copy of w, [slab][tap][row][32] (bf16 3x3 layers, k_pack_conv_sm), or nullptr: the 8x8 LDS-DMA kernel reads it
     int w_slab_stride;     // LDS-DMA 3x3 kernels: elements between the 32-channel slabs of a weight row (0 = 32: the plain [tap][row][cin] matrix;
                            // slab-major copies [slab][tap][row][32], ConvW::w_sm, make every 1 KB DMA piece one contiguous run of whole cache lines)
+    int w_split;           // conv_dmax3_kernel.h: 1 = w is the pre-split copy (k_pack_conv_sm, f32x3): no split pass over the weight sub-stages
     int w_rows;            // informational: rows of the weight matrix (columns >= Cout are never stored)
     unsigned x0_bytes, x1_bytes, w_bytes;   // extents for the buffer descriptors (reads past them return 0)
     const float* bias;     // [Cout] or nullptr

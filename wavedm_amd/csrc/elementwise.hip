@@ -618,7 +618,38 @@ __global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restri
         dst[id] = (__bf16)v;
     }
 }
-int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s) {
+// f32x3 mode (conv_dmax3_kernel.h): OIHW f32 3x3 -> [tap][rows_total][cin] with every 16-channel group (64 bytes) already split and laid out as the kernel's
+// LDS rows: [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] bf16 (hi = RNE(w), lo = RNE(w - hi)) -- the kernel then DMAs weight sub-stages ready to multiply
+__global__ __launch_bounds__(256) void pack_conv_x3_kernel(const float* __restrict__ w, int cout, int cin, unsigned* __restrict__ dst, int rows_total) {
+    const int upr = cin / 4;                                     // 4-channel units per row
+    const long long total = (long long)9 * rows_total * upr;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int u = (int)(id % upr);
+        const int o = (int)((id / upr) % rows_total);
+        const int tap = (int)(id / ((long long)upr * rows_total));
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (o < cout) for (int e = 0; e < 4; ++e) x[e] = w[((long long)o * cin + u * 4 + e) * 9 + tap];
+        unsigned hi[2], lo[2];
+        for (int h = 0; h < 2; ++h) {
+            const unsigned ph = TI<__bf16>::pack2(x[2 * h], x[2 * h + 1]);
+            hi[h] = ph;
+            lo[h] = TI<__bf16>::pack2(x[2 * h] - __uint_as_float(ph << 16), x[2 * h + 1] - __uint_as_float(ph & 0xffff0000u));
+        }
+        const int grp = u >> 2, uu = u & 3;
+        unsigned* row = dst + ((long long)tap * rows_total + o) * cin + grp * 16;      // dwords: one per fp32 element of the plain matrix
+        unsigned* ph = row + (uu >> 1) * 4 + (uu & 1) * 2;
+        ph[0] = hi[0]; ph[1] = hi[1]; ph[8] = lo[0]; ph[9] = lo[1];
+    }
+}
+int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype) {
+    if (dtype == WDM_F32X3) {
+        if (cin % 16) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 16", cin);
+        const long long total = (long long)9 * rows_total * (cin / 4);
+        hipLaunchKernelGGL(pack_conv_x3_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 65535)), dim3(256), 0, s, w_oihw, cout, cin, (unsigned*)dst, rows_total);
+        WDM_HIP(hipGetLastError());
+        return WDM_OK;
+    }
+
     if (cin % 32) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 32", cin);
     const long long total = (long long)9 * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
