@@ -288,3 +288,28 @@ def test_f32x3_resblock_on_the_lds_dma_kernel(gu, cin, cout, B, H, cat):
     assert torch.equal(y, run()[0])
     if H != 8:
         assert torch.equal(y, _with({"WDM_WSM": "0"}, run)[0])                        # weights split in the kernel instead of the pre-split copy: same bits
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(256, 256, 2, 32), (512, 512, 3, 16), (768, 768, 5, 8), (128, 192, 2, 16)])
+def test_f32x3_upsample_in_sub_pixel_form(gu, cin, cout, B, H):
+    """conv_up4x3_kernel.h (f32x3 mode: four 2x2-tap phase convs with pre-summed, pre-split weights) against the 9-tap register-staged form (WDM_UP4=0) and
+    torch fp32: the pre-summing reassociates the taps, everything stays inside the f32x3 bound."""
+    from wavedm_amd import _lib
+    w = gu.seeded((cout, cin, 3, 3), 51) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 52) * 0.1
+    x = gu.seeded((B, cin, H, H), 53)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+
+    def run():
+        _lib.prof_enable(True)
+        out = gu.conv(w, b, 2, x, "f32x3")
+        names = [e["kernel"].split("|")[0] for e in _lib.prof_report()]
+        _lib.prof_enable(False)
+        return out, names
+    y, k = run()
+    y0, k0 = _with({"WDM_UP4": "0"}, run)
+    assert any(n.startswith("convup4x3") for n in k) and any(n.startswith("conv_3x3ups") for n in k0), (k, k0)
+    e, e0 = rel_linf(y, ref), rel_linf(y0, ref)
+    print(f"f32x3 upsample {cin}->{cout} @{H}: sub-pixel {e:.2e}  9-tap {e0:.2e}")
+    assert e <= 2e-5 and e0 <= 2e-5
+    assert torch.equal(y, run()[0])

@@ -158,8 +158,8 @@ int wdm_conv_forward(wdm_handle* h, const float* w, const float* b, int cin, int
     WDM_TRY(pack_conv_w(sc, w, b, cin, cout, mode == MODE_P1 ? 1 : 3, dtype, c.s, &cw));
     if (mode == MODE_UPS && conv_up4_eligible(dtype, H, W, cin, cout)) {       // same selection as the UNet executor: sub-pixel taps next to the 3x3 ones
         char* up4;
-        WDM_TRY(sc.get<char>((size_t)16 * cw.rows_pad * cin * 2, &up4));
-        WDM_TRY(k_pack_up4(w, cout, cin, up4, cw.rows_pad, c.s));
+        WDM_TRY(sc.get<char>((size_t)16 * cw.rows_pad * cin * dsize(dtype), &up4));
+        WDM_TRY(k_pack_up4(w, cout, cin, up4, cw.rows_pad, c.s, dtype));
         cw.w_up4 = up4;
     }
     Tens t0, out;

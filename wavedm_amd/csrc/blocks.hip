@@ -114,7 +114,7 @@ const EnvCfg& env_cfg() {
 }
 
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
-    return env_cfg().up4 && dtype == WDM_BF16 && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+    return env_cfg().up4 && (dtype == WDM_BF16 || (dtype == WDM_F32X3 && env_cfg().x3_dma)) && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
 }
 
 int launch_conv(const ConvArgs& a0, int mode, int dtype, hipStream_t s) {

@@ -154,7 +154,7 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
 // (f32x3 mode: the same slot holds the pre-split copy of conv_dmax3_kernel.h, plain [tap][row][cin] order, 16-channel groups as [hi | hi | lo | lo])
 inline bool conv_sm_eligible(int dtype, int k, int cin) { return (dtype == WDM_BF16 && k == 3 && cin % 32 == 0) || (dtype == WDM_F32X3 && k == 3 && cin % 16 == 0); }
 int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
-int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s);
+int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout);      // sub-pixel Upsample kernel applies to this low-resolution map
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);

@@ -5,4 +5,5 @@
 #define WDM_HAS_DMAX3 1
 #include "conv_dmax3_kernel.h"
 #include "conv_dma8x3_kernel.h"
+#include "conv_up4x3_kernel.h"
 #include "conv_dispatch.inc"

@@ -677,7 +677,46 @@ __global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__
         dst[id] = (__bf16)v;
     }
 }
-int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s) {
+// f32x3 mode (conv_up4x3_kernel.h): the same 16 pre-summed taps (fp32 sums), every 16-channel group split and laid out as [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
+__global__ __launch_bounds__(256) void pack_up4_x3_kernel(const float* __restrict__ w, int cout, int cin, unsigned* __restrict__ dst, int rows_total) {
+    const int upr = cin / 4;
+    const long long total = (long long)16 * rows_total * upr;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int u = (int)(id % upr);
+        const int o = (int)((id / upr) % rows_total);
+        const int t = (int)(id / ((long long)upr * rows_total));       // phase * 4 + dy' * 2 + dx'
+        const int py = t >> 3, px = (t >> 2) & 1, dyl = (t >> 1) & 1, dxl = t & 1;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (o < cout) {
+            const int y0 = py == 0 ? (dyl == 0 ? 0 : 1) : (dyl == 0 ? 0 : 2), y1 = py == 0 ? (dyl == 0 ? 0 : 2) : (dyl == 0 ? 1 : 2);
+            const int x0 = px == 0 ? (dxl == 0 ? 0 : 1) : (dxl == 0 ? 0 : 2), x1 = px == 0 ? (dxl == 0 ? 0 : 2) : (dxl == 0 ? 1 : 2);
+            for (int e = 0; e < 4; ++e) {
+                const float* p = w + ((long long)o * cin + u * 4 + e) * 9;
+                float v = 0.f;
+                for (int ty = y0; ty <= y1; ++ty)
+                    for (int tx = x0; tx <= x1; ++tx) v += p[ty * 3 + tx];
+                x[e] = v;
+            }
+        }
+        unsigned hi[2], lo[2];
+        for (int h = 0; h < 2; ++h) {
+            const unsigned ph = TI<__bf16>::pack2(x[2 * h], x[2 * h + 1]);
+            hi[h] = ph;
+            lo[h] = TI<__bf16>::pack2(x[2 * h] - __uint_as_float(ph << 16), x[2 * h + 1] - __uint_as_float(ph & 0xffff0000u));
+        }
+        const int grp = u >> 2, uu = u & 3;
+        unsigned* q = dst + ((long long)t * rows_total + o) * cin + grp * 16 + (uu >> 1) * 4 + (uu & 1) * 2;
+        q[0] = hi[0]; q[1] = hi[1]; q[8] = lo[0]; q[9] = lo[1];
+    }
+}
+int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype) {
+    if (dtype == WDM_F32X3) {
+        if (cin % 16) WDM_FAIL(WDM_EINVAL, "k_pack_up4: cin %d is not a multiple of 16", cin);
+        const long long tot = (long long)16 * rows_total * (cin / 4);
+        hipLaunchKernelGGL(pack_up4_x3_kernel, dim3(nblocks(tot, 256) > 16384 ? 16384 : nblocks(tot, 256)), dim3(256), 0, s, w_oihw, cout, cin, (unsigned*)dst, rows_total);
+        WDM_HIP(hipGetLastError());
+        return WDM_OK;
+    }
     const long long total = (long long)16 * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
     hipLaunchKernelGGL(pack_up4_kernel, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst, rows_total);

@@ -205,8 +205,8 @@ int wdm_unet::build() {
             for (int b = 0; b <= nrb; ++b) up_attn[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != 0) {
             up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3, 0, false);
-            if (cfg.dtype == WDM_BF16 && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h, next to the 3x3 ones
-                up_us[l].up4_off = take((size_t)16 * up_us[l].rows_pad * block_in * 2);
+            if ((cfg.dtype == WDM_BF16 || cfg.dtype == WDM_F32X3) && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h / conv_up4x3_kernel.h, next to the 3x3 ones
+                up_us[l].up4_off = take((size_t)16 * up_us[l].rows_pad * block_in * dsize(cfg.dtype));
                 params[index["up." + std::to_string(l) + ".upsample.conv.weight"]].up4_off = up_us[l].up4_off;
             }
             res *= 2;
@@ -418,7 +418,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
         if (p.sm_off) WDM_TRY(k_pack_conv_sm(dev_src, cout, cin, u->packed + p.sm_off, p.rows_total, s, u->cfg.dtype));
-        if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s));
+        if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s, u->cfg.dtype));
     } else {
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
     }
