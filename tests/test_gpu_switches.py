@@ -313,3 +313,37 @@ def test_f32x3_upsample_in_sub_pixel_form(gu, cin, cout, B, H):
     print(f"f32x3 upsample {cin}->{cout} @{H}: sub-pixel {e:.2e}  9-tap {e0:.2e}")
     assert e <= 2e-5 and e0 <= 2e-5
     assert torch.equal(y, run()[0])
+
+
+def test_f32x3_gemms_on_the_lds_dma_kernel(gu):
+    """conv_gemmx3_kernel.h (f32x3 mode: both operands split hi / lo in LDS, two 16x16x32 MFMAs per product) against the register-staged f32x3 kernel
+    (WDM_X3_GEMM=0) and exact fp32: plain 1x1 convs (one and two K stages' worth of odd sizes, Cout not a multiple of the tile) and a whole AttnBlock
+    (projections, Q.K^T and P.V with per-image operands, proj_out with residual)."""
+    from wavedm_amd import _lib
+
+    def run(f):
+        _lib.prof_enable(True)
+        out = f()
+        names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+        _lib.prof_enable(False)
+        return out, names
+    for cin, cout, B, H in ((512, 512, 3, 16), (160, 224, 2, 32), (1280, 512, 2, 16), (128, 128, 1, 64)):
+        w = gu.seeded((cout, cin, 1, 1), 61) / cin ** 0.5
+        b = gu.seeded((cout,), 62) * 0.1
+        x = gu.seeded((B, cin, H, H), 63)
+        ref = torch.nn.functional.conv2d(x, w, b)
+        (y, k), (y0, k0) = run(lambda: gu.conv(w, b, 3, x, "f32x3")), _with({"WDM_X3_GEMM": "0"}, lambda: run(lambda: gu.conv(w, b, 3, x, "f32x3")))
+        assert any(n.startswith("gemmx3") for n in k) and not any(n.startswith("gemmx3") for n in k0), (k, k0)
+        assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5, (cin, cout, rel_linf(y, ref))
+    for C, B in ((512, 3), (256, 2)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for kk in ("q", "k", "v", "proj_out"):
+            shapes[kk + ".weight"] = (C, C, 1, 1)
+            shapes[kk + ".bias"] = (C,)
+        sd = gu.blk_sd("at", shapes)
+        x = gu.seeded((B, C, 16, 16), 9)
+        (y, k), (y0, k0) = run(lambda: gu.attn(sd, "at", x, "f32x3")), _with({"WDM_X3_GEMM": "0"}, lambda: run(lambda: gu.attn(sd, "at", x, "f32x3")))
+        ref = gu.attn(sd, "at", x, "f32")
+        assert sum(n.startswith("gemmx3") for n in k) >= 1 and not any(n.startswith("gemmx3") for n in k0), (k, k0)
+        print(f"f32x3 attn C={C}: dma {rel_linf(y, ref):.2e}  register-staged {rel_linf(y0, ref):.2e}")
+        assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5

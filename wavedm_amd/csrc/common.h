@@ -208,6 +208,7 @@ struct EnvCfg {
     int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)
     int gemm8 = 0;        // WDM_GEMM8=1: 1x1 convs on 8 x 8 maps (middle AttnBlock) on the LDS-DMA GEMM kernel, four images per tile -- measured 25.8 vs 22.4 us
                           // (768->768) and 23.0 vs 23.9 (768->1536): 96 / 192 workgroups of a 12-step K loop are latency, not staging
+    int x3_gemm = 1;      // WDM_X3_GEMM=0: the f32x3 mode's 1x1 convs / batched GEMMs on the register-staged kernel
     int x3_dma = 1;       // WDM_X3_DMA=0: the f32x3 mode's 3x3 convs on the register-staged kernel
     int s2_dma = 1;       // WDM_S2_DMA=0: Downsample convs on the register-staged kernel; 2 / 3: 128- / 64-column tiles wherever the shape allows
     int gn_tile = 1;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h)

@@ -6,4 +6,5 @@
 #include "conv_dmax3_kernel.h"
 #include "conv_dma8x3_kernel.h"
 #include "conv_up4x3_kernel.h"
+#include "conv_gemmx3_kernel.h"
 #include "conv_dispatch.inc"
