@@ -37,6 +37,16 @@ def short(name: str) -> str:
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
     if m:
         return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn{32 * int(m.group(3) or 4)}w8_bf16"
+    if "conv_dmax3_kernel" in name:
+        return "convdmax3_3x3s1_t16x16x1_bn128w8_f32x3"
+    m = re.search(r"conv_dma8x3_kernelILi(\d+)E", name)
+    if m:
+        return f"convdma8x3_3x3s1_t8x8x2_bn{m.group(1)}w4_f32x3"
+    m = re.search(r"conv_up4x3_kernelILi(\d+)ELi(\d+)E", name)
+    if m:
+        return f"convup4x3_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn128w8_f32x3"
+    if "conv_gemmx3_kernel" in name:
+        return "gemmx3_1x1_t16x16x1_bn128_f32x3"
     m = re.search(r"conv_s2_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"convs2_3x3s2_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn{32 * int(m.group(3))}w8_bf16"
