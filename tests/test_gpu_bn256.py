@@ -19,10 +19,14 @@ def gu():
 
 
 def _modes(f, modes=("0", "2", "3", "1")):
+    """f() under every tiling switch.  WDM_GN_TILE=1 throughout: whether conv1 of a 16 x 16 ResnetBlock can also normalise for conv2 depends on the tile it runs
+    on (only the 256 x 128 one holds a whole image) -- these tests are about the tilings' bits, not about where the norm is computed."""
     from wavedm_amd import _lib
     old = os.environ.get("WDM_BN256")
+    old_t = os.environ.get("WDM_GN_TILE")
     out = []
     try:
+        os.environ["WDM_GN_TILE"] = "1"
         for m in modes:
             os.environ["WDM_BN256"] = m
             _lib.env_refresh()
@@ -32,6 +36,10 @@ def _modes(f, modes=("0", "2", "3", "1")):
             os.environ.pop("WDM_BN256", None)
         else:
             os.environ["WDM_BN256"] = old
+        if old_t is None:
+            os.environ.pop("WDM_GN_TILE", None)
+        else:
+            os.environ["WDM_GN_TILE"] = old_t
         _lib.env_refresh()
     return out
 

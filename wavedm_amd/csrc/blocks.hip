@@ -95,7 +95,7 @@ void env_cfg_refresh() {
     c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
     c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->grid_gn = num("WDM_GRID_GN", 1);
     c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = flag("WDM_GN_TILE", 1); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
+    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = num("WDM_GN_TILE", 2); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
     c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
     c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
@@ -299,6 +299,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     const bool pass = x0.H * x0.W <= gn_pass_max_hw();
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
+    const NormW* on12 = env_cfg().gn_tile >= 2 ? &w.n2 : nullptr;      // WDM_GN_TILE=2: conv1 also normalises for conv2 on the larger maps where its kernel can
     if (pass) {
         Tens a1;
         WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
@@ -307,12 +308,16 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         free_tens(c, a1);
     } else if (gn_inline_ok(c, x0, x1, w.cout)) {
         // conv1's GroupNorm finalised in conv1's own prologue from the producer's group partials: no gn_finalize launch (gn_inline.h)
-        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n1));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n1,
+                         nullptr, on12, 1));
     } else {
         WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
-        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, on12, 1));
         c.ar->free(sc1); c.ar->free(sh1);
     }
+    // conv1 wrote act(norm2(h)) itself (16 x 16 maps: its tile is the whole image): conv2 then runs WITHOUT the prologue, as on the 8 x 8 maps -- every one of
+    // its N tiles would otherwise repeat the GroupNorm+SiLU of the same halo slabs (Cout / 128 = 4 times on these maps)
+    const bool pre2 = !pass && t1.nrm != nullptr && t1.nrm_for == w.n2.g && t1.nrm_silu == 1;
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
     // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h unless WDM_DMA8=0)
@@ -323,7 +328,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         WDM_TRY(run_conv(c, w.nin, MODE_P1, x0, x1, nullptr, nullptr, nullptr, 0, 0, nullptr, &sct, Y_NHWC, nullptr));
         res = &sct;
     }
-    if (pass) {
+    if (pass || pre2) {
         Tens a2;
         WDM_TRY(materialize_gn_silu(c, w.n2, t1, nullptr, &a2));
         if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu));

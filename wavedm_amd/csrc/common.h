@@ -211,7 +211,8 @@ struct EnvCfg {
     int x3_gemm = 1;      // WDM_X3_GEMM=0: the f32x3 mode's 1x1 convs / batched GEMMs on the register-staged kernel
     int x3_dma = 1;       // WDM_X3_DMA=0: the f32x3 mode's 3x3 convs on the register-staged kernel
     int s2_dma = 1;       // WDM_S2_DMA=0: Downsample convs on the register-staged kernel; 2 / 3: 128- / 64-column tiles wherever the shape allows
-    int gn_tile = 1;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h)
+    int gn_tile = 2;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h); 1: only for the consumers
+                          // that normalise in a pass anyway; 2: also conv1 -> norm2 of the ResnetBlocks on 16 x 16 maps (conv2 then runs without its prologue)
     int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
     int up4_gn = 1;       // WDM_UP4_GN=2|4|8: N-tile groups per XCD of the 8 x 8 sub-pixel upsample kernel
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
