@@ -93,7 +93,7 @@ void env_cfg_refresh() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->up4 = flag("WDM_UP4", 1); c->dma8 = flag("WDM_DMA8", 1); c->dma8_bn64 = num("WDM_DMA8_BN", 0) == 64; c->dma8_gn = num("WDM_DMA8_GN", 4);
     c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
-    c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->grid_gn = num("WDM_GRID_GN", 1);
+    c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->gn_pass_cat_hw = num("WDM_GN_PASS_CAT_HW", 0); c->grid_gn = num("WDM_GRID_GN", 1);
     c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = num("WDM_GN_TILE", 2); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
     c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
@@ -300,11 +300,15 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
     const NormW* on12 = env_cfg().gn_tile >= 2 ? &w.n2 : nullptr;      // WDM_GN_TILE=2: conv1 also normalises for conv2 on the larger maps where its kernel can
-    if (pass) {
+    // channel-concat inputs on maps up to gn_pass_cat_hw pixels (the 16 x 16 up blocks: 768 ... 1280 -> 512): one pass writes act(norm1([x0 | x1])) and conv1 runs
+    // without the prologue -- its Cout / 128 = 4 N tiles each repeat the GroupNorm+SiLU of all K slabs, and these inputs need a gn_finalize launch anyway.
+    // Measured null at 16 x 16 (616.2 / 616.9 vs 617.4 / 616.8 img/s), -1.5 % with the 32 x 32 maps included: off by default (WDM_GN_PASS_CAT_HW=256 to compare)
+    const bool pass1 = pass || (x1 != nullptr && x0.H * x0.W <= env_cfg().gn_pass_cat_hw && c.dtype == WDM_BF16);
+    if (pass1) {
         Tens a1;
         WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
         WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr,
-                         nullptr, &w.n2, 1));            // ... and act(norm2(h)) for conv2 where the kernel can (8 x 8 maps: conv_dma8_kernel.h)
+                         nullptr, pass ? &w.n2 : on12, 1));      // ... and act(norm2(h)) for conv2 where the kernel can (8 x 8 maps: conv_dma8_kernel.h; 16 x 16: on12)
         free_tens(c, a1);
     } else if (gn_inline_ok(c, x0, x1, w.cout)) {
         // conv1's GroupNorm finalised in conv1's own prologue from the producer's group partials: no gn_finalize launch (gn_inline.h)

@@ -192,6 +192,7 @@ struct EnvCfg {
     int attn_vt = 1;      // WDM_ATTN_VT=0: V^T by the conv with the channel-major epilogue
     int fuse_nin = 1;     // WDM_FUSE_NIN=0: 1x1 shortcut as its own GEMM
     int gn_pass_hw = 64;  // WDM_GN_PASS_HW=<pixels>: largest map that gets the GroupNorm+SiLU pass
+    int gn_pass_cat_hw = 0;   // WDM_GN_PASS_CAT_HW=<pixels>: ... for conv1 of a ResnetBlock with a channel-concat input (0: never)
     int grid_gn = 1;      // WDM_GRID_GN=1|2|4|8: XCD tile order of the other conv kernels
     int conv_dma = 1;     // WDM_CONV_DMA=0: no LDS-DMA 3x3 kernel
     int gemm = 1;         // WDM_GEMM=0: 1x1 convs on the register-staged kernel
