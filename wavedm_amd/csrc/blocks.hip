@@ -325,7 +325,8 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
     // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h unless WDM_DMA8=0)
-    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && env_cfg().dma8)) && c.dtype == WDM_BF16 && fuse_shortcut_enabled() &&
+    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && env_cfg().dma8 && c.dtype == WDM_BF16)) &&
+                          (c.dtype == WDM_BF16 || (c.dtype == WDM_F32X3 && env_cfg().x3_dma && x0.H % 16 == 0 && x0.W % 16 == 0)) && fuse_shortcut_enabled() &&
                           conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
     if (w.has_nin && !fuse_nin) {

@@ -14,10 +14,11 @@
 //   * a product is TWO v_mfma_f32_16x16x32_bf16 (the full-rate instruction; the K = 16 form the register-staged kernel uses runs at half its rate):
 //     the weight operand is the row as stored, k-groups [w_hi | w_lo] x 16 channels, the pixel operand its hi half twice, then its lo half twice --
 //     (w_hi + w_lo) p_hi + (w_hi + w_lo) p_lo: all four terms (the three-MFMA form drops w_lo p_lo), 32 MFMA cycles per 16 channels instead of 48.
-// No fused shortcut, no in-prologue GroupNorm finalize (bf16 only).  LDS map as conv_dma_kernel.h: A[2] = 2 x 24 KB, ring 4 x 24 KB at 48 KB, scale / shift
+// No in-prologue GroupNorm finalize (bf16 only); the fused 1x1 shortcut is a second phase running conv_gemmx3_kernel.h's K loop.  LDS map as conv_dma_kernel.h: A[2] = 2 x 24 KB, ring 4 x 24 KB at 48 KB, scale / shift
 // at 144 KB.
 #pragma once
 #include "conv_kernel.h"
+#include "conv_gemmx3_kernel.h"
 
 namespace wdm {
 
@@ -265,6 +266,29 @@ __global__ __launch_bounds__(512, 2) void conv_dmax3_kernel(const ConvArgs a) {
 #undef WDM_X3_BARRIER
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // no DMA may land on what follows
     __builtin_amdgcn_sched_barrier(0);
+    // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1; unet.py:134-137), as in
+    // conv_dma_kernel.h -- here the K loop of conv_gemmx3_kernel.h over the tile's 256 pixels: x_shortcut + h is one fp32 accumulator, the shortcut tensor never exists
+    if (a.sx0 != nullptr) {
+        static_assert(GemmX3Cfg::NBUF * GemmX3Cfg::STAGE <= C::LDS_BYTES && GemmX3Cfg::WM == WM && GemmX3Cfg::WN == WN, "shortcut phase");
+        unsigned g_a0[4], g_a1[4], g_b[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + (lane >> 3);
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
+            g_a0[j] = gp * (unsigned)(a.sxs0 * 4) + (unsigned)(u * 16);
+            g_a1[j] = gp * (unsigned)(a.sxs1 * 4) + (unsigned)(u * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + (lane >> 3);
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            g_b[j] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 4 + u * 16) : OOB;
+        }
+        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
+        gemmx3_phase(acc, smem, q_s0, q_s1, q_sw, g_a0, g_a1, g_b, a.sC0, (a.sC0 + a.sC1) / GemmX3Cfg::BK, lane, wave, wave_m, wave_n);
+    }
     conv_epilogue<float, 16, TW, 4, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 

@@ -22,51 +22,17 @@ struct GemmX3Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-__global__ __launch_bounds__(512, 2) void conv_gemmx3_kernel(const ConvArgs a) {
+// The K loop of the GEMM as a phase other kernels can run too (conv_dmax3_kernel.h: the ResnetBlock's 1x1 shortcut accumulated into conv2's tile): rows of the A
+// operand = the tile's 256 pixels at a_v0 / a_v1 (per-lane byte offsets into q_a0 / q_a1 of this wave's chunks; the second tensor takes over at channel C0),
+// rows of the B operand at b_v into q_w, nk stages of 32 channels; every LDS byte from `smem` up to 3 stages is overwritten.  The caller has drained its DMA
+// queue and passed a barrier.
+typedef int gx3_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gemmx3_phase(f32x4 (&acc)[4][4], char* smem, const gx3_i32x4& q_a0, const gx3_i32x4& q_a1, const gx3_i32x4& q_w, const unsigned (&a_v0)[4],
+                                             const unsigned (&a_v1)[4], const unsigned (&b_v)[2], int C0, int nk, int lane, int wave, int wave_m, int wave_n) {
     using C = GemmX3Cfg;
-    constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave / C::WAVES_N, wave_n = wave % C::WAVES_N;
-
-    int mt, nt;
-    if (!conv_decode_tile(a, blockIdx.x, mt, nt)) return;
-    const int n0 = nt * BN;
-    int img0, oy0, ox0, tile_in_img = 0;
-    conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
-
-    constexpr unsigned OOB = 0xFFFF0000u;
-    unsigned a_v0[A_CPW], a_v1[A_CPW], b_v[B_CPW];
-#pragma unroll
-    for (int j = 0; j < A_CPW; ++j) {
-        const int row = (wave * A_CPW + j) * 8 + (lane >> 3);
-        const int u = (lane & 7) ^ ((row >> 1) & 7);
-        const int iy = oy0 + row / TW, ix = ox0 + row % TW;
-        const bool ok = img0 < a.B && iy < a.Hin && ix < a.Win;
-        const unsigned gp = (unsigned)((conv_x_img(a, img0) * a.Hin + iy) * a.Win + ix);
-        a_v0[j] = ok ? gp * (unsigned)(a.xs0 * 4) + (unsigned)(u * 16) : OOB;
-        a_v1[j] = ok ? gp * (unsigned)(a.xs1 * 4) + (unsigned)(u * 16) : OOB;
-    }
-#pragma unroll
-    for (int j = 0; j < B_CPW; ++j) {
-        const int row = (wave * B_CPW + j) * 8 + (lane >> 3);
-        const int u = (lane & 7) ^ ((row >> 1) & 7);
-        const int n = n0 + row;
-        b_v[j] = n < a.w_rows ? (unsigned)(n * a.w_row_stride * 4 + u * 16) : OOB;
-    }
-
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto make_q = [](const void* p, unsigned bytes) __attribute__((always_inline)) {
-        const unsigned long long v = (unsigned long long)p;
-        return i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
-    };
-    const i32x4 q_x0 = make_q(a.x0, a.x0_bytes), q_x1 = make_q(a.x1 ? a.x1 : a.x0, a.x1_bytes);
-    const i32x4 q_w = make_q((const float*)a.w + conv_w_img_offset(a, img0), a.w_bytes);
+    constexpr int WM = C::WM, WN = C::WN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto dma16 = [&](const i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
+    auto dma16 = [&](const gx3_i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -76,12 +42,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemmx3_kernel(const ConvArgs a) {
     auto issue = [&](int k, int buf) __attribute__((always_inline)) {
         const int c = k * C::BK;
         const unsigned base = lds0 + buf * STAGE;
-        if (c < a.C0) {
+        if (c < C0) {
 #pragma unroll
-            for (int j = 0; j < A_CPW; ++j) dma16(q_x0, base + (wave * A_CPW + j) * 1024, a_v0[j], c * 4);
+            for (int j = 0; j < A_CPW; ++j) dma16(q_a0, base + (wave * A_CPW + j) * 1024, a_v0[j], c * 4);
         } else {
 #pragma unroll
-            for (int j = 0; j < A_CPW; ++j) dma16(q_x1, base + (wave * A_CPW + j) * 1024, a_v1[j], (c - a.C0) * 4);
+            for (int j = 0; j < A_CPW; ++j) dma16(q_a1, base + (wave * A_CPW + j) * 1024, a_v1[j], (c - C0) * 4);
         }
 #pragma unroll
         for (int j = 0; j < B_CPW; ++j) dma16(q_w, base + A_BYTES + (wave * B_CPW + j) * 1024, b_v[j], c * 4);
@@ -121,15 +87,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemmx3_kernel(const ConvArgs a) {
         b_off[ks] = A_BYTES + (wave_n * WN * 16 + (lane & 15)) * 128 + (((ks * 4 + ku) ^ sw) << 4);
     }
 
-    f32x4 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     // K loop: stage k + 2 is requested behind the barrier that frees its buffer; behind the MFMAs of stage k the wave waits for ITS pieces of stage k + 1 and
     // splits them; the next barrier publishes the split.
-    const int nk = a.Cin / C::BK;
     constexpr int CPW = A_CPW + B_CPW;
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -167,6 +126,56 @@ __global__ __launch_bounds__(512, 2) void conv_gemmx3_kernel(const ConvArgs a) {
         }
         buf = nb;
     }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_gemmx3_kernel(const ConvArgs a) {
+    using C = GemmX3Cfg;
+    constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / C::WAVES_N, wave_n = wave % C::WAVES_N;
+
+    int mt, nt;
+    if (!conv_decode_tile(a, blockIdx.x, mt, nt)) return;
+    const int n0 = nt * BN;
+    int img0, oy0, ox0, tile_in_img = 0;
+    conv_decode_image<TH, TW>(a, mt, img0, tile_in_img, oy0, ox0);
+
+    constexpr unsigned OOB = 0xFFFF0000u;
+    unsigned a_v0[A_CPW], a_v1[A_CPW], b_v[B_CPW];
+#pragma unroll
+    for (int j = 0; j < A_CPW; ++j) {
+        const int row = (wave * A_CPW + j) * 8 + (lane >> 3);
+        const int u = (lane & 7) ^ ((row >> 1) & 7);
+        const int iy = oy0 + row / TW, ix = ox0 + row % TW;
+        const bool ok = img0 < a.B && iy < a.Hin && ix < a.Win;
+        const unsigned gp = (unsigned)((conv_x_img(a, img0) * a.Hin + iy) * a.Win + ix);
+        a_v0[j] = ok ? gp * (unsigned)(a.xs0 * 4) + (unsigned)(u * 16) : OOB;
+        a_v1[j] = ok ? gp * (unsigned)(a.xs1 * 4) + (unsigned)(u * 16) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < B_CPW; ++j) {
+        const int row = (wave * B_CPW + j) * 8 + (lane >> 3);
+        const int u = (lane & 7) ^ ((row >> 1) & 7);
+        const int n = n0 + row;
+        b_v[j] = n < a.w_rows ? (unsigned)(n * a.w_row_stride * 4 + u * 16) : OOB;
+    }
+
+    auto make_q = [](const void* p, unsigned bytes) __attribute__((always_inline)) {
+        const unsigned long long v = (unsigned long long)p;
+        return gx3_i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+    };
+    const gx3_i32x4 q_x0 = make_q(a.x0, a.x0_bytes), q_x1 = make_q(a.x1 ? a.x1 : a.x0, a.x1_bytes);
+    const gx3_i32x4 q_w = make_q((const float*)a.w + conv_w_img_offset(a, img0), a.w_bytes);
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemmx3_phase(acc, smem, q_x0, q_x1, q_w, a_v0, a_v1, b_v, a.C0, a.Cin / C::BK, lane, wave, wave_m, wave_n);
     __syncthreads();
     conv_epilogue<float, TH, TW, WM, WN, 4>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
