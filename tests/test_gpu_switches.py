@@ -385,3 +385,27 @@ def test_conv1_normalises_for_conv2_on_16x16_maps(gu, cin, cout, B, cat):
     assert rel_linf(y, ref) <= gu.TOL["bf16"] and rel_linf(y1, ref) <= gu.TOL["bf16"]
     assert torch.equal(y, run()[0])
     assert torch.equal(y[1:2], gu.resblock(sd, "rb", x0[1:2].contiguous(), x1[1:2].contiguous() if cat else None, t[1:2].contiguous(), "bf16"))     # batch-independent
+
+
+def test_in_tile_groupnorm_in_the_f32x3_mode(gu):
+    """The f32x3 LDS-DMA kernels keep their epilogue tiles too (gn_out_tail<float>): conv1 -> norm2 of an 8x8 ResnetBlock bit-identical to the gn_finalize_apply
+    pass (WDM_GN_TILE=0), and on a 16x16 map conv2 without its prologue (WDM_GN_TILE=2) inside the f32x3 bound."""
+    from wavedm_amd import _lib
+    for c, H, B in ((768, 8, 3), (512, 16, 2)):
+        shapes = {"norm1.weight": (c,), "norm1.bias": (c,), "conv1.weight": (c, c, 3, 3), "conv1.bias": (c,), "temb_proj.weight": (c, 512),
+                  "temb_proj.bias": (c,), "norm2.weight": (c,), "norm2.bias": (c,), "conv2.weight": (c, c, 3, 3), "conv2.bias": (c,)}
+        sd = gu.blk_sd("rb", shapes)
+        x, t = gu.seeded((B, c, H, H), 5), gu.seeded((B, 512), 6)
+
+        def run():
+            _lib.prof_enable(True)
+            out = gu.resblock(sd, "rb", x, None, t, "f32x3")
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+            _lib.prof_enable(False)
+            return out, names
+        y, k = run()
+        y0, k0 = _with({"WDM_GN_TILE": "0"}, run)
+        ref = gu.resblock(sd, "rb", x, None, t, "f32")
+        if H == 8:
+            assert torch.equal(y, y0) and sum("gn_finalize_apply" in n for n in k) + 1 == sum("gn_finalize_apply" in n for n in k0), (k, k0)
+        assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5 and rel_linf(y, y0) <= 2e-5

@@ -5,6 +5,7 @@
 // v_mfma_f32_16x16x32_bf16 (weight row [w_hi | w_lo] against the pixel's hi half twice, then its lo half twice).
 #pragma once
 #include "conv_kernel.h"
+#include "gn_group.h"
 
 namespace wdm {
 
@@ -191,7 +192,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma8x3_kernel(const ConvArgs a) {
 #undef WDM_D8X3_WAIT
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // no DMA may land on what follows
     __builtin_amdgcn_sched_barrier(0);
-    conv_epilogue<float, TH, TW, WM, WN, C::NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0);
+    // the tile is NI whole images x BN columns: the consumer's act(GroupNorm(y)) from here when it asked for it (gn_group.h)
+    using G = GnTailGeom<TH, TW, WM, WN, C::NJ, C::WAVES_N>;
+    static_assert(G::total_bytes(C::NWAVES, NI, BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
+    float4* keep_tab = a.yn != nullptr ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
+    conv_epilogue<float, TH, TW, WM, WN, C::NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, 0, 0, n0, 0, 0, EpiNoHook(), true, keep_tab, BN);
+    if (a.yn != nullptr) gn_out_tail<float, C::NTHREADS, G, C::WAVES_N, WN, BN>(a, img0, NI, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(NI, BN)), tid);
 }
 
 }  // namespace wdm

@@ -19,6 +19,7 @@
 #pragma once
 #include "conv_kernel.h"
 #include "conv_gemmx3_kernel.h"
+#include "gn_group.h"
 
 namespace wdm {
 
@@ -289,7 +290,12 @@ __global__ __launch_bounds__(512, 2) void conv_dmax3_kernel(const ConvArgs a) {
         const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
         gemmx3_phase(acc, smem, q_s0, q_s1, q_sw, g_a0, g_a1, g_b, a.sC0, (a.sC0 + a.sC1) / GemmX3Cfg::BK, lane, wave, wave_m, wave_n);
     }
-    conv_epilogue<float, 16, TW, 4, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    // 16 x 16 maps: the tile is one whole image x BN columns -- the consumer's act(GroupNorm(y)) from here when it asked for it (gn_group.h; host check)
+    using G = GnTailGeom<16, TW, 4, WN, WN, C::WAVES_N>;
+    static_assert(G::total_bytes(C::NWAVES, 1, BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
+    float4* keep_tab = a.yn != nullptr ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
+    conv_epilogue<float, 16, TW, 4, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, BN);
+    if (a.yn != nullptr) gn_out_tail<float, C::NTHREADS, G, C::WAVES_N, WN, BN>(a, img0, 1, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(1, BN)), tid);
 }
 
 }  // namespace wdm

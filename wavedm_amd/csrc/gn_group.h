@@ -106,7 +106,7 @@ __device__ __forceinline__ uint4 gn_apply_vec(const uint4& u, const float* sc, c
 // Everything stays in LDS: the epilogue keeps every pass's tile of final values and a table of the tile's per-(image, slab, column) partials
 // (conv_epilogue_w: keep_tab); wave k finalises (image, group) pair k, k + NW, ... with gn_group_stats -- the reduction of the stand-alone kernels over
 // the same float4 partials, hence the same mean / rstd bits -- and all threads apply scale / shift (+ SiLU) with the arithmetic of gn_apply_vec to the
-// values the statistics pass left in the tiles (exactly the bf16 values stored to y).  A first form re-read y and the statistics from L2 after waiting
+// values the statistics pass left in the tiles (exactly the values stored to y: bf16-rounded, or the fp32 ones of the f32 / f32x3 modes).  A first form re-read y and the statistics from L2 after waiting
 // for the stores: 6-8 us of exposed round trips per launch (the whole chip is in the tail at the same time) -- as much as the launch it replaced.
 // Geometry of the epilogue tiles: wave (wave_m, wave_n) holds rows [wave_m * EROWS, +EROWS) x its 16 WN columns, ECOLS = 16 NJ of them per pass.
 // ------------------------------------------------------------------------------------------------
@@ -124,8 +124,7 @@ template <typename T, int NTHREADS, class G, int WAVES_N, int WN, int BN, class 
 __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int n0, char* smem, const float4* keep_tab, float* tab, int tid) {
     // (every index below divides by compile-time constants only: with run-time divisors the address arithmetic of the apply loop -- four ~35-instruction
     // divisions per vector -- cost more than the arithmetic itself)
-    constexpr int VEC = 8, NW = NTHREADS / 64, bn = BN, HW = G::HW, ncols = BN;      // host check: Cout % BN == 0, gw divides BN
-    static_assert(TI<T>::VEC == 8, "bf16 outputs");
+    constexpr int VEC = TI<T>::VEC, ES = 16 / VEC, NW = NTHREADS / 64, bn = BN, HW = G::HW, ncols = BN;      // host check: Cout % BN == 0, gw divides BN
     const int lane = tid & 63, wave = tid >> 6;
     const int gw = a.Cout >> 5;
     const int ng = ncols / gw;
@@ -143,7 +142,7 @@ __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int
     __syncthreads();
     constexpr int cols = ncols / VEC;
     const int nv = ni * HW * cols;
-    const __amdgpu_buffer_rsrc_t r_n = __builtin_amdgcn_make_buffer_rsrc(a.yn, 0, (int)(unsigned)((long long)a.B * HW * a.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_n = __builtin_amdgcn_make_buffer_rsrc(a.yn, 0, (int)(unsigned)((long long)a.B * HW * a.Cout * ES), 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const float* tiles = (const float*)smem;
     for (int id = tid; id < nv; id += NTHREADS) {
@@ -152,11 +151,12 @@ __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int
         const int wn = col / (16 * WN), cw = col - wn * (16 * WN);
         const int ps = cw / G::ECOLS, c = cw - ps * G::ECOLS;
         const float* src = tiles + ((ps * NW + wm * WAVES_N + wn) * G::EROWS + r) * G::ESTR + c;
-        const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) { const float4 v = *(const float4*)(src + e); f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w; }
         const int il = m / HW;
         const uint4 o = gn_apply_f8<T>(f, &tab[il * bn + col], &tab[(nimg + il) * bn + col], a.on_silu);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_n, (int)(unsigned)((((long long)img0 * HW + m) * a.Cout + n0 + col) * 2), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_n, (int)(unsigned)((((long long)img0 * HW + m) * a.Cout + n0 + col) * ES), 0, 0);
     }
 }
 
