@@ -16,12 +16,12 @@ import pandas as pd
 
 def short(name: str) -> str:
     """Mangled kernel name (rocprofv3 -M) -> readable id; conv_kernel<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>."""
-    m = re.search(r"conv_kernelI(DF16b|f)((?:Li\d+E)+)", name)
+    m = re.search(r"conv_kernelI(DF16b|f|NS_7f32x3_tE)((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(2))]
         if len(a) in (8, 9):
             mode = {0: "3x3s1", 1: "3x3s2", 2: "3x3ups", 3: "1x1"}[a[0]]
-            ty = "bf16" if m.group(1) == "DF16b" else "f32"
+            ty = {"DF16b": "bf16", "f": "f32"}.get(m.group(1), "f32x3")
             return f"conv_{mode}_t{a[1]}x{a[2]}x{a[3]}_bn{16 * a[7] * a[5]}_{ty}"
     m = re.search(r"conv_dma_kernelI((?:Li\d+E)+)", name)
     if m:
