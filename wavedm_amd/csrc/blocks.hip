@@ -377,7 +377,9 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
     // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
     const bool vt_gemm = env_cfg().attn_vt != 0;
-    const bool v_as_gemm = fused && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
+    // (f32x3 mode, unfused core: the same form on conv_gemmx3_kernel.h, the bias then rides on the P.V product -- softmax rows sum to one)
+    const bool x3_vt = c.dtype == WDM_F32X3 && env_cfg().x3_dma && env_cfg().x3_gemm && N == 256;
+    const bool v_as_gemm = (fused || x3_vt) && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
     if (v_as_gemm) {
         if (!c.dry) {
             ConvArgs a{};
@@ -441,6 +443,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
         p.w = vT; p.w_tap_stride = 0; p.w_img_stride = (long long)C * N; p.w_row_stride = N; p.w_rows = C;
         p.w_bytes = (unsigned)((size_t)C * N * es);
         p.alpha = 1.0f;
+        p.bias = v_as_gemm ? w.v.b : nullptr;            // V^T came without its bias (GEMM form): sum_j P[i][j] (v[j][c] + b[c]) = (P v)[i][c] + b[c]
         p.y = o.p; p.y_mode = Y_NHWC; p.y_s = C;
         WDM_TRY(launch_conv(p, MODE_P1, c.dtype, c.s));
     }
