@@ -14,7 +14,7 @@
 #include "gn_group.h"
 
 #ifndef WDM_D8ABL
-#define WDM_D8ABL 0         // tools/dma8_ablate.hip: 2 = no MFMAs, 16 (with 2) = no fragment reads either, 4 = no halo DMA, 8 = no weight DMA
+#define WDM_D8ABL 0         // tools/dma8_ablate.hip: 2 = no MFMAs, 16 (with 2) = no fragment reads either, 4 = no halo DMA, 8 = no weight DMA, 32 = no barriers in the K loop (timing only)
 #endif
 
 namespace wdm {
@@ -164,7 +164,8 @@ __global__ __launch_bounds__((ConvDma8Cfg<BN_, NI_>::NTHREADS), 2) void conv_dma
                 }
         }
     };
-#define WDM_DMA8_SYNC(N) do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WDM_DMA8_SYNC(N) do { if (WDM_D8ABL & 32) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); /* ablation: no barrier (wrong results, timing only) */ \
+                              else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     issue_a(0);
     issue_b(0, 0, 0);
