@@ -11,10 +11,12 @@ import wavedm_amd                                    # noqa: E402
 from wavedm_amd import procedural as P              # noqa: E402
 
 torch.set_grad_enabled(False)
-cfg = P.raindrop_wavelet_config()
+R = int(os.environ.get("R", "64"))                  # wavelet-domain patch size: 64 (BASELINE configs[1]) or 128 (configs[2])
+cfg = P.raindrop_wavelet_config(image_size=R) if R != 64 else P.raindrop_wavelet_config()
 sd = P.procedural_state_dict(cfg, seed=61)
 g = torch.Generator().manual_seed(5)
-x = torch.randn(128, 96, 64, 64, generator=g)
+SIZES = (1, 2, 3, 7, 33, 64, 100, 128) if R == 64 else (1, 2, 5, 16, 33)
+x = torch.randn(max(SIZES), 96, R, R, generator=g)
 t = torch.tensor([470.0])
 bad = 0
 for dtype in sys.argv[1:] or ["bf16", "f32x3", "f32"]:
@@ -22,7 +24,7 @@ for dtype in sys.argv[1:] or ["bf16", "f32x3", "f32"]:
     net.load_state_dict(sd, strict=True)
     net = net.cuda()
     ref = None
-    for B in (1, 2, 3, 7, 33, 64, 100, 128):
+    for B in SIZES:
         if dtype == "f32" and B > 33:
             continue
         y = net(x[:B].cuda(), t)[:1].cpu()
