@@ -17,10 +17,11 @@ SW = {"WDM_GN_TILE": "012", "WDM_GN_INLINE": "01", "WDM_GN_FUSED": "01", "WDM_BN
       "WDM_WSM": "01", "WDM_X3_DMA": "01", "WDM_X3_GEMM": "01", "WDM_GEMM_PAIR": "01", "WDM_DMA8_BN": ["48", "64"], "WDM_GN_PASS_CAT_HW": ["0", "256"]}
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = random.Random(7)
-cfg = P.raindrop_wavelet_config()
+R = int(os.environ.get("R", "64"))
+cfg = P.raindrop_wavelet_config(image_size=R) if R != 64 else P.raindrop_wavelet_config()
 sd = P.procedural_state_dict(cfg, seed=61)
 g = torch.Generator().manual_seed(5)
-x = torch.randn(3, 96, 64, 64, generator=g).cuda()
+x = torch.randn(3, 96, R, R, generator=g).cuda()
 t = torch.tensor([470.0])
 bad = 0
 for dtype, tol in (("bf16", 3e-2), ("f32x3", 1e-4)):
