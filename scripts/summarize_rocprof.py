@@ -45,6 +45,9 @@ def short(name: str) -> str:
     m = re.search(r"conv_up4x3_kernelILi(\d+)ELi(\d+)E", name)
     if m:
         return f"convup4x3_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn128w8_f32x3"
+    m = re.search(r"conv_s2x3_kernelILi(\d+)E", name)
+    if m:
+        return f"convs2x3_3x3s2_t16x16x1_bn{32 * int(m.group(1))}w8_f32x3"
     if "conv_gemmx3_kernel" in name:
         return "gemmx3_1x1_t16x16x1_bn128_f32x3"
     m = re.search(r"conv_s2_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)

@@ -409,3 +409,25 @@ def test_in_tile_groupnorm_in_the_f32x3_mode(gu):
         if H == 8:
             assert torch.equal(y, y0) and sum("gn_finalize_apply" in n for n in k) + 1 == sum("gn_finalize_apply" in n for n in k0), (k, k0)
         assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5 and rel_linf(y, y0) <= 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 128, 3, 64), (256, 256, 2, 32), (96, 192, 2, 32)])
+def test_f32x3_downsample_on_the_lds_dma_kernel(gu, cin, cout, B, H):
+    """conv_s2x3_kernel.h (f32x3 mode: the four-phase Downsample kernel with halo and weights split in LDS) against torch fp32 and the register-staged f32x3 form."""
+    from wavedm_amd import _lib
+    w = gu.seeded((cout, cin, 3, 3), 41) / (cin * 9) ** 0.5
+    b = gu.seeded((cout,), 42) * 0.1
+    x = gu.seeded((B, cin, H, H), 43)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+
+    def run():
+        _lib.prof_enable(True)
+        out = gu.conv(w, b, 1, x, "f32x3")
+        names = [e["kernel"].split("|")[0] for e in _lib.prof_report()]
+        _lib.prof_enable(False)
+        return out, names
+    y, k = run()
+    y0, k0 = _with({"WDM_S2_DMA": "0"}, run)
+    assert any(n.startswith("convs2x3") for n in k) and any(n.startswith("conv_3x3s2") for n in k0), (k, k0)
+    assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5
+    assert torch.equal(y, run()[0])

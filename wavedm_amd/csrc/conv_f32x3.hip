@@ -7,4 +7,5 @@
 #include "conv_dma8x3_kernel.h"
 #include "conv_up4x3_kernel.h"
 #include "conv_gemmx3_kernel.h"
+#include "conv_s2x3_kernel.h"
 #include "conv_dispatch.inc"
