@@ -299,6 +299,12 @@ int wdm_prof_report(wdm_prof_entry* out, int max_entries, int* n_entries);
  * (No counterpart in the reference: csrc/common.h EnvCfg.) */
 int wdm_env_refresh(void);
 
+/* ---- concurrent streams -------------------------------------------------------------------------
+ * A caller that keeps n independent forward calls in flight on n HIP streams (wavedm_amd/sampling.py: chunks of independent crops) says so here: the tile
+ * choices that follow the workgroup count of ONE launch ("256-column tiles where they still fill the chip") then count n launches side by side.  Those
+ * alternatives write the same bits, so this changes speed only.  n = 1 (default): one launch owns the chip.  (No counterpart in the reference.) */
+int wdm_set_concurrent_streams(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,7 @@ def lib():
         "wdm_upsample_add": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
         "wdm_prof_enable": (i, [i]),
         "wdm_env_refresh": (i, []),
+        "wdm_set_concurrent_streams": (i, [i]),
         "wdm_prof_report": (i, [C.POINTER(ProfEntry), i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
@@ -137,11 +138,26 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
             "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_dwt_fwd_affine", "wdm_dwt_inv_compose", "wdm_conv2d_direct", "wdm_groupnorm", "wdm_cross_attention", "wdm_upsample_add",
-            "wdm_prof_enable", "wdm_prof_report", "wdm_env_refresh"]
+            "wdm_prof_enable", "wdm_prof_report", "wdm_env_refresh", "wdm_set_concurrent_streams"]
+
+
+_PROF_ON = False
 
 
 def prof_enable(on: bool):
+    global _PROF_ON
     check(lib().wdm_prof_enable(1 if on else 0))
+    _PROF_ON = bool(on)
+
+
+def prof_on() -> bool:
+    """Per-launch timing is on (events around every launch on the launch stream): samplers then keep to one stream."""
+    return _PROF_ON
+
+
+def set_concurrent_streams(n: int):
+    """Tell the library how many forward calls the caller keeps in flight side by side (include/wavedm.h)."""
+    check(lib().wdm_set_concurrent_streams(int(n)))
 
 
 def env_refresh():

@@ -160,6 +160,7 @@ int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dt
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
 
 // ---- live kernel timing (prof.hip): HIP events on the launch stream around every conv launch ------
+int concurrent_streams();      // prof.hip: wdm_set_concurrent_streams
 bool prof_enabled();
 void prof_begin(hipStream_t s, const char* kernel, double flops, double bytes);
 void prof_end(hipStream_t s);

@@ -5,6 +5,7 @@
 #include <map>
 #include <string>
 
+#include <atomic>
 #include "common.h"
 
 namespace wdm {
@@ -27,6 +28,8 @@ void prof_begin(hipStream_t s, const char* kernel, double flops, double bytes) {
     g_recs.push_back(r);
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+static std::atomic<int> g_concurrent_streams{1};
+int concurrent_streams() { return g_concurrent_streams.load(std::memory_order_relaxed); }
 }  // namespace wdm
 
 using namespace wdm;
@@ -42,6 +45,13 @@ int wdm_prof_enable(int on) {
 int wdm_env_refresh(void) {
     env_cfg();                // make sure the first-use initialisation has happened, then overwrite it
     env_cfg_refresh();
+    return WDM_OK;
+}
+
+// Launches the caller keeps in flight side by side (include/wavedm.h); read by the workgroup-count rules of conv_dispatch.inc (concurrent_streams())
+int wdm_set_concurrent_streams(int n) {
+    if (n < 1 || n > 64) WDM_FAIL(WDM_EINVAL, "wdm_set_concurrent_streams: %d out of range (1 .. 64)", n);
+    g_concurrent_streams.store(n, std::memory_order_relaxed);
     return WDM_OK;
 }
 

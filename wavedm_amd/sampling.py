@@ -59,8 +59,14 @@ def overlapping_grid_indices(h, w, output_size, r=None):
     return h_list, w_list
 
 
+def _chunk_streams(dev, n):
+    """Side streams of the chunked sampler: fresh ones from torch's pool per call.  (Measured, round 3: the SAME four streams used pass after pass ran 35 %
+    slower than one stream on every box tried, streams taken round-robin from the pool mostly did not -- see EXPERIMENTS.md; this is why `streams` is opt-in.)"""
+    return [torch.cuda.Stream(device=dev) for _ in range(n)]
+
+
 def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None,
-                patch_group=None):
+                patch_group=None, streams=None):
     """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
 
     x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
@@ -74,6 +80,12 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
     stop_at: opt-in early stop: a negative index k means "x0_preds[k] is all the caller needs", so the
           |k|-1 steps after it -- which the reference computes and discards (restoration.py:108 uses [-5]) -- are skipped;
           the lists are padded with None so indices keep their meaning.  Default None = run every step like the reference.
+    streams: OPT-IN (default WAVEDM_STREAMS or 1).  Independent crops (corners=None) are split into this many chunks, each walking its whole trajectory on a
+          HIP stream of its own (own UNet workspace), so that one chunk's kernels can fill the launch boundaries and tails of the others'.  Per-image results do
+          not depend on the batch an image sits in: the same bits as one stream (tests/test_gpu_unet.py).  Measured with 4 streams: +5 % on a box whose
+          single-stream rate was 120 img/s, +-0 on one at 127, and -35 % whenever the same four streams are reused pass after pass or five or more are
+          active (the device has four hardware queues) -- not understood well enough to be a default.  Patch lists (overlap sums couple an image's patches
+          every step) and per-launch profiling always run on one stream.
     patch_group: a torch.distributed process group (or True for the default group) = patch-sharded latency mode
           (SURVEY.md §8e-ii): the patch list is split contiguously over the ranks, each rank runs the UNet on its patches,
           and ONE all-reduce(sum) per step (RCCL) combines partial sums and overlap counts before the DDIM update, which every
@@ -137,6 +149,23 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         temb = unet.temb_table(t_dev, B=min(max(n, 1), max_batch)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
         xs, x0_preds = [x], []
         xt = x
+        # chunks of independent crops, one HIP stream each (see `streams`)
+        chunks = None
+        ns = int(os.environ.get("WAVEDM_STREAMS", "1")) if streams is None else int(streams)
+        if os.environ.get("WDM_GRAPH", "0") not in ("", "0"):
+            ns = 1                                                    # a replayed graph has one workspace baked in
+        if corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on():
+            per = -(-n // ns)
+            main = torch.cuda.current_stream()
+            chunks = []
+            pool = _chunk_streams(dev, ns)
+            for ci, lo in enumerate(range(0, n, per)):
+                sc = pool[ci]
+                sc.wait_stream(main)                                  # inputs, x96's constant channels and the temb table are ready
+                chunks.append((lo, min(lo + per, n), sc))
+            for ci, (lo, hi, _) in enumerate(chunks):                # the chunks' workspaces, allocated here on the caller's stream
+                for i in range(lo, hi, max_batch):
+                    unet.workspace(min(i + max_batch, hi) - i, dev, ci)
         n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
         assert 1 <= n_run <= len(seq), f"stop_at={stop_at} out of range for {len(seq)} steps"
         for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
@@ -147,12 +176,31 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
             s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
             san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
+            x0 = torch.empty_like(x)
+            xn = torch.empty_like(x)
+            if chunks is not None:
+                # independent crops: every chunk's step on its own stream (same kernels, same per-image bits)
+                _lib.set_concurrent_streams(len(chunks))              # tile rules that count one launch's workgroups count the chunks' together
+                try:
+                    for ci, (lo, hi, sc) in enumerate(chunks):
+                        with torch.cuda.stream(sc):
+                            stc = sc.cuda_stream
+                            _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt[lo:hi]), pc, H, W, None, hi - lo, p, _lib.ptr(x96[lo:hi]), cin, ncond, unet._dtype_code, stc))
+                            for i in range(lo, hi, max_batch):
+                                j = min(i + max_batch, hi)
+                                unet.forward_nhwc(x96[i:j], t_dev[k:k + 1], eps[i:j], temb_row=None if temb is None else temb[k], ws_slot=ci)
+                            _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps[lo:hi]), None, hi - lo, p, _lib.ptr(xt[lo:hi]), hi - lo, H, W, s1m, sa, san, c2,
+                                                         _lib.ptr(x0[lo:hi]), _lib.ptr(xn[lo:hi]), stc))
+                finally:
+                    _lib.set_concurrent_streams(1)
+                x0_preds.append(x0)
+                xs.append(xn)
+                xt = xn
+                continue
             if n:
                 _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
             for i in range(0, n, max_batch):
                 unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
-            x0 = torch.empty_like(x)
-            xn = torch.empty_like(x)
             if sharded:
                 _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
                 dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
@@ -163,6 +211,9 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             x0_preds.append(x0)
             xs.append(xn)
             xt = xn
+        if chunks is not None:
+            for (_, _, sc) in chunks:
+                torch.cuda.current_stream().wait_stream(sc)            # the caller's stream sees every chunk's results
         if keep != "all":
             S = len(x0_preds)
             x0_preds = [t if (i - S) in keep else None for i, t in enumerate(x0_preds)]

@@ -204,13 +204,15 @@ class DiffusionUNet(nn.Module):
             _lib.check(L.wdm_unet_set_packed(self._u, _lib.ptr(self._packed), self._packed.numel()))
         return self._packed
 
-    def workspace(self, B, device):
-        key = (B, str(device))
+    def workspace(self, B, device, slot=0):
+        """Workspace of a forward call at batch B.  slot: calls that may be in flight at the same time (one per HIP stream: sampling.ddim_sample) need one each."""
+        key = (B, str(device), slot)
         if key not in self._ws:
             n = int(_lib.lib().wdm_unet_workspace_bytes(self._u, B))
             if n == 0:
                 raise RuntimeError("wdm_unet_workspace_bytes failed: " + _lib.lib().wdm_last_error().decode())
-            self._ws = {key: torch.empty(n + 256, dtype=torch.uint8, device=device)}   # keep only the latest size
+            self._ws = {k: v for k, v in self._ws.items() if k[0] == B and k[1] == str(device)}      # keep only the latest size (every slot of it)
+            self._ws[key] = torch.empty(n + 256, dtype=torch.uint8, device=device)
         return self._ws[key]
 
     # ---- forward -------------------------------------------------------------------------------
@@ -226,15 +228,15 @@ class DiffusionUNet(nn.Module):
             _lib.check(L.wdm_unet_temb_table(self._u, _lib.ptr(t), int(t.numel()), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         return out
 
-    def forward_nhwc(self, x96, t, eps_out, temb_row=None):
+    def forward_nhwc(self, x96, t, eps_out, temb_row=None, ws_slot=0):
         """x96: (B,R,R,Cin) NHWC in the compute dtype; t: (n,) fp32 device; eps_out: (B,out_ch,R,R) fp32.
-        temb_row: one row of temb_table() for this call's timestep (then t is not read)."""
+        temb_row: one row of temb_table() for this call's timestep (then t is not read).  ws_slot: see workspace()."""
         B = x96.shape[0]
         assert x96.is_contiguous() and x96.dtype == self._torch_dtype and tuple(x96.shape[1:]) == (self.resolution, self.resolution, self.in_channels)
         assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and tuple(eps_out.shape) == (B, self.out_ch, self.resolution, self.resolution)
         self.pack_weights()
         with torch.cuda.device(x96.device):
-            ws = self.workspace(B, x96.device)
+            ws = self.workspace(B, x96.device, ws_slot)
             if temb_row is not None:
                 assert temb_row.dtype == torch.float32 and temb_row.is_cuda and temb_row.is_contiguous() and temb_row.dim() == 1
                 _lib.check(_lib.lib().wdm_unet_forward_temb(self._u, _lib.ptr(x96), _lib.ptr(temb_row), B, _lib.ptr(eps_out),
