@@ -14,6 +14,7 @@
 #include "conv_dma_kernel.h"
 #include "conv_dma256_kernel.h"
 #include "conv_dmap_kernel.h"
+#include "conv_dma2_kernel.h"
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -23,12 +24,12 @@ static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 
 struct Shape { int B, H, Cin, Cout, pro, res, sc; };      // sc: channels of the fused 1x1 shortcut's input (0 = none)
 typedef void (*kern_t)(const ConvArgs);
-struct Variant { const char* name; kern_t kern; int lds, th, bn, persist; };
+struct Variant { const char* name; kern_t kern; int lds, th, bn, persist, threads = 512; };
 
 static float time_kernel(const Variant& v, int grid, const ConvArgs& a, int it) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(v.kern, dim3(grid), dim3(512), v.lds, 0, a);
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), v.lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
@@ -49,10 +50,11 @@ int main(int argc, char** argv) {
     using C256h = ConvDma256Cfg<2, 4, 4, 4, 8>;
     std::vector<Variant> vars = {
         {"t256x128", conv_dma_kernel<4, 2, 4, 4>, C128::LDS_BYTES, 16, 128, 0},
-        {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16>, C256::LDS_BYTES, 16, 256, 0},
-        {"t128x256", conv_dma256_kernel<2, 4, 4, 4, 8>, C256h::LDS_BYTES, 8, 256, 0},
-        {"persist2", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
-        {"persist1", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
+        {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16, true>, C256::LDS_BYTES, 16, 256, 0},
+        {"t256x256F", conv_dma256_kernel<4, 2, 4, 8, 16, false>, C256::LDS_BYTES, 16, 256, 0},
+        {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
+        {"persistF", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
+        {"two80", conv_dma2_kernel, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
     };
     if (getenv("ONLY")) { std::vector<Variant> keep = {vars[0]}; for (size_t i = 1; i < vars.size(); ++i) if (strstr(getenv("ONLY"), vars[i].name)) keep.push_back(vars[i]); vars = keep; }
     const int NCU = getenv("NCU") ? atoi(getenv("NCU")) : 256;
@@ -121,8 +123,14 @@ int main(int argc, char** argv) {
             if (vars[i].persist && grid[i] > NCU) grid[i] = NCU;
         }
         std::vector<int> skip(NV, 0);
-        for (int v = 0; v < NV; ++v) skip[v] = vars[v].bn == 256 && Cout % 256 != 0;
-        for (int v = 0; v < NV; ++v) if (!skip[v]) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(512), vars[v].lds, 0, aa[v]);
+        for (int v = 0; v < NV; ++v) skip[v] = (vars[v].bn == 256 && Cout % 256 != 0) || (!strcmp(vars[v].name, "two80") && (sh.sc != 0 || Cin > 1024))
+#ifdef WDM_NO_PACK
+            || !strcmp(vars[v].name, "persist1") || !strcmp(vars[v].name, "t256x256");
+#else
+            || (!strcmp(vars[v].name, "persist1") && sh.res) || (!strcmp(vars[v].name, "persistF") && !sh.res)
+            || (!strcmp(vars[v].name, "t256x256") && sh.res) || (!strcmp(vars[v].name, "t256x256F") && !sh.res);
+#endif
+        for (int v = 0; v < NV; ++v) if (!skip[v]) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(vars[v].threads), vars[v].lds, 0, aa[v]);
         CK(hipDeviceSynchronize());
         std::vector<unsigned short> h0(ny), h1(ny);
         std::vector<unsigned> s0((size_t)B * nslab * Cout * 4), s1(s0.size());

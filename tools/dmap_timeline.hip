@@ -7,10 +7,10 @@
 #include <vector>
 #include "conv_dmap_kernel.h"
 using namespace wdm;
-#ifndef TWO_PASS_V
-#define TWO_PASS_V true
+#ifndef PACKED_V
+#define PACKED_V true
 #endif
-#define KERN conv_dmap_kernel<TWO_PASS_V>
+#define KERN conv_dmap_kernel<PACKED_V>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {

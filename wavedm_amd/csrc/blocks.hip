@@ -95,7 +95,7 @@ void env_cfg_refresh() {
     c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
     c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->gn_pass_cat_hw = num("WDM_GN_PASS_CAT_HW", 0); c->grid_gn = num("WDM_GRID_GN", 1);
     c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->epi_direct = flag("WDM_EPI_DIRECT", 0); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = num("WDM_GN_TILE", 2); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
+    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = num("WDM_GN_TILE", 2); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
     c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
     c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
@@ -118,13 +118,11 @@ bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
 }
 
 int launch_conv(const ConvArgs& a0, int mode, int dtype, hipStream_t s) {
-    ConvArgs a = a0;
-    a.no_direct = env_cfg().epi_direct ? 0 : 1;
+    const ConvArgs& a = a0;
     return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
 }
 int launch_gemm_pair(const ConvArgs& a0, const ConvArgs& b0, int dtype, hipStream_t s) {
-    ConvArgs a = a0, b = b0;
-    a.no_direct = b.no_direct = env_cfg().epi_direct ? 0 : 1;
+    const ConvArgs &a = a0, &b = b0;
     return dtype == WDM_BF16 ? launch_gemm_pair_bf16(a, b, s) : dtype == WDM_F32X3 ? launch_gemm_pair_f32x3(a, b, s) : launch_gemm_pair_f32(a, b, s);
 }
 

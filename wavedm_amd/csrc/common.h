@@ -204,7 +204,6 @@ struct EnvCfg {
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
     int attn_proj = 1;    // WDM_ATTN_PROJ=0: proj_out of the AttnBlocks as its own GEMM launch
-    int epi_direct = 0;   // WDM_EPI_DIRECT=1: GroupNorm partial statistics of residual-free convs straight from the accumulators (measured 3.5 % slower)
     int gemm_pair = 0;    // WDM_GEMM_PAIR=1: the AttnBlock's q|k and V^T GEMMs in one launch (same bits; measured +-0.1 %: 256 + 128 workgroups of 160 KB
                           // LDS each still run one after the other on the 256 CUs, only a kernel boundary is saved)
     int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)

@@ -49,7 +49,8 @@ struct ConvDma256Cfg {
     static_assert(B_OFF + 2 * B_SUB <= SC_OFF && EPI_BYTES <= SC_OFF && G_NBUF * G_STAGE <= SC_OFF && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_>
+// PACKED: the launcher's conv_epilogue_can_pack(a) (one epilogue form per kernel: with both, the 128 accumulator registers leave the allocator no room)
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_, bool PACKED = false>
 __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     using C = ConvDma256Cfg<WAVES_M_, WAVES_N_, WM_, WN_, TH_>;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     const int vy = oy0 & ~15;                                   // origin of the 16 x 16 tile this tile belongs to
     const int v_tile = (vy >> 4) * twn + (ox0 >> 4);
     const int v_wave_m = TH == 16 ? wave_m : ((oy0 & 8) >> 2) + wave_m;
-    conv_epilogue<T, 16, TW, 4, WN, 4>(a, acc, smem, true, wave, lane, v_wave_m, wave_n, img0, vy, ox0, n0, v_tile);      // WN / 4 passes of 64 columns
+    conv_epilogue<T, 16, TW, 4, WN, 4, EpiNoHook, false, (PACKED ? 2 : 0)>(a, acc, smem, true, wave, lane, v_wave_m, wave_n, img0, vy, ox0, n0, v_tile);      // WN / 4 passes of 64 columns
 }
 
 }  // namespace wdm

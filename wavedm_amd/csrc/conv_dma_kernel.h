@@ -477,7 +477,7 @@ __global__ __launch_bounds__((64 * WAVES_M_ * WAVES_N_), (WAVES_M_ * WAVES_N_ ==
         using G = GnTailGeom<16, TW, 4, WN, WN, C::WAVES_N>;
         static_assert(G::total_bytes(C::NWAVES, 1, C::BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
         float4* keep_tab = a.yn != nullptr ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
-        conv_epilogue<T, 16, TW, 4, WN, WN>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, C::BN);
+        conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, 1>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, C::BN);
         if (a.yn != nullptr) gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, C::BN>(a, img0, 1, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(1, C::BN)), tid);
 #ifdef WDM_WG_CLOCK
         if (threadIdx.x == 0) { a.ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); a.ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }

@@ -7,9 +7,11 @@
 //
 // What changes against conv_dma_kernel.h (same K order, same epilogue arithmetic and statistics slabs => the same bits):
 //   * sub-stage g lives in ring slot (g + 2) & 3, so that the next tile's first sub-stages go to slots 2 and 3;
-//   * the epilogue runs in two passes of 32 columns (72 KB of LDS at [24 KB, 96 KB) = A[1], slots 0 and 1) instead of one pass over 136 KB, leaving
-//     A[0], slots 2 and 3 and the table free for the next tile's DMAs, which are issued from the end of the epilogue's first pass
-//     (conv_epilogue_w: hook) -- the second pass and the statistics run while they are in flight;
+//   * the epilogue sits at [24 KB, ...): convs without a residual operand leave through the packed form (conv_epilogue_packed: a bf16 tile, 64 KB =
+//     A[1], slot 0 and part of slot 1), which leaves A[0], slots 2 and 3 and the table free: the next tile's WHOLE head (table, halo slab 0, weight
+//     sub-stages 0 and 1) goes out from the hook, i.e. as soon as the tile's stores are issued, and the statistics pass runs while it is in flight;
+//     convs with a residual keep the one-pass fp32 form (136 KB): only A[0] stays free, only the halo goes out from the hook, table and weights follow
+//     the epilogue.  (Round 3 had a two-pass fp32 form with the packed form's LDS footprint: its second pass cost more than the head start won.)
 //   * the vector-memory counter also counts the epilogue's stores: the counted waits of the next tile's prologue / K loop only get more
 //     conservative (loads retire in order among themselves), never unsafe.
 #pragma once
@@ -27,14 +29,14 @@ namespace wdm {
 struct ConvDmaPCfg {
     using B = ConvDmaCfg;
     static constexpr int EPI_OFF = B::A_BYTES;                           // 24 KB
-    static constexpr int EPI_BYTES = 8 * 64 * (32 + 4) * 4;              // 72 KB: two-column-fragment passes
+    static constexpr int EPI_BYTES = 8 * EPI_PACK_TILE;                  // 64 KB: the packed form's bf16 tile
     static constexpr int LDS_BYTES = B::LDS_BYTES;
-    static_assert(EPI_OFF + EPI_BYTES <= B::B_OFF + 2 * B::B_SUB, "epilogue must leave A[0] and slots 2, 3 alone");
+    static_assert(EPI_OFF + EPI_BYTES <= B::B_OFF + 2 * B::B_SUB, "the packed epilogue must leave A[0] and slots 2, 3 alone");
 };
 
-// TWO_PASS = false: the ONE-pass epilogue of conv_dma_kernel.h at [24 KB, 160 KB) -- only A[0] stays free, so only the next tile's halo slab 0 (the
-// HBM-resident, 64-byte-gathered part of the head) goes out from the hook; table and weights follow the epilogue.
-template <bool TWO_PASS>
+// PACKED: the launcher's conv_epilogue_can_pack(a) -- a template parameter because with both epilogue forms in one kernel the register allocator spills
+// (37 VGPRs; the fp32 form lost 15 % on the residual layers)
+template <bool PACKED>
 __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_value) {
     using C = ConvDmaCfg;
     // Every argument is read through the kernarg segment pointer, laundered per phase: read from the by-value parameter, all scalar loads are hoisted
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
     const int nslab = ap->Cin / C::BK;
     const int wslab = ap->w_slab_stride ? ap->w_slab_stride : C::BK;
     const bool pro = ap->pro != 0;
+    constexpr bool packed = PACKED;
     const int nvb = 8 * ap->ntiles * ((ap->mtiles + 7) >> 3);               // virtual blocks of the non-persistent launch (grid_gn == 1)
 
     // ---- per-tile state: the tile being computed (scalars) and the DMA offsets of the tile whose operands are requested next
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
     };
     // head of a tile's DMA stream: table (two pieces per wave), halo slab 0, weight sub-stages 0 and 1 (slots 2, 3)
     // head of a tile's DMA stream: table (or the image's group partials, gn_inline.h), halo slab 0, weight sub-stages 0 and 1 (slots 2, 3).
-    // part 0: everything (first tile) | 1: halo only (one-pass hook) | 2: table / partials + weights (one-pass, behind the epilogue: the table region and
-    // A[1], the partials' scratch, lie under the epilogue tile) | 3: two-pass hook: everything but the partials | 4: the partials (two-pass, behind the epilogue)
+    // part 0: everything (first tile) | 1: halo only (fp32 epilogue's hook) | 2: table / partials + weights (fp32 form, behind the epilogue: the table region and
+    // A[1], the partials' scratch, lie under the epilogue tile) | 3: packed form's hook: everything but the partials | 4: the partials (packed form, behind the epilogue)
     auto issue_head = [&](int part) __attribute__((always_inline)) {
         const bool inl = ap->gin != nullptr;
         if (pro && inl && (part == 0 || part == 2 || part == 4)) gn_inline_issue<C::MAX_CIN>(*ap, img0, wave, lane, lds0 + C::A_BYTES, lds0 + C::SC_OFF, dma16, make_q);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         if (pro) {
             // table (or the image's group partials) and this lane's halo pieces landed: younger are the three weight sub-stages -- except in the
             // two-pass form after the first tile, where the table / partials go out behind the epilogue, i.e. behind sub-stages 0 and 1
-            if (TWO_PASS && tile_it > 0 && ap->gin != nullptr) WDM_DMA_SYNC(BCP); else WDM_DMA_SYNC(3 * BCP);
+            if (packed && tile_it > 0 && ap->gin != nullptr) WDM_DMA_SYNC(BCP); else WDM_DMA_SYNC(3 * BCP);
             WDM_PTS(1);
             if (ap->gin != nullptr) {
                 gn_inline_table<C::MAX_CIN>((const float*)(smem + C::A_BYTES), (float*)(smem + C::SC_OFF), ap->gin_nslab, ap->Cin, ap->Hin * ap->Win, ap->gn_eps, tid);
@@ -329,10 +332,9 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         WDM_PTS(4);
         if (more) setup(mt2, nt2);
         WDM_PTS(5);
-        auto hook = [&]() __attribute__((always_inline)) { if (more) issue_head(TWO_PASS ? 3 : 1); };
+        auto hook = [&]() __attribute__((always_inline)) { if (more) { if (packed) issue_head(3); else issue_head(1); } };
         WDM_RELOAD_ARGS();
-        if constexpr (TWO_PASS) conv_epilogue<T, 16, TW, 4, WN, 2, decltype(hook), true>(*ap, acc, smem + ConvDmaPCfg::EPI_OFF, true, wave, lane, wave_m, wave_n, c_img0, c_oy0, c_ox0, c_n0, c_tile, 0, hook, false);
-        else conv_epilogue<T, 16, TW, 4, WN, WN, decltype(hook), false>(*ap, acc, smem + ConvDmaPCfg::EPI_OFF, true, wave, lane, wave_m, wave_n, c_img0, c_oy0, c_ox0, c_n0, c_tile, 0, hook, false);
+        conv_epilogue<T, 16, TW, 4, WN, WN, decltype(hook), false, (PACKED ? 2 : 0)>(*ap, acc, smem + ConvDmaPCfg::EPI_OFF, true, wave, lane, wave_m, wave_n, c_img0, c_oy0, c_ox0, c_n0, c_tile, 0, hook, false);
         WDM_PTS(6);
 #ifdef WDM_EPI_TS
         if (!more && threadIdx.x == 0) { ap->ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); ap->ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
         __builtin_amdgcn_sched_barrier(0);
         WDM_PTS(7);
         ++tile_it;
-        if constexpr (!TWO_PASS) issue_head(2); else issue_head(4);
+        if (packed) issue_head(4); else issue_head(2);
     }
 #undef WDM_DMA_SYNC
 #undef WDM_RELOAD_ARGS

@@ -102,7 +102,6 @@ struct ConvArgs {
     float on_eps;
     int on_silu;
     int* query_yn;         // host only: when set, the launcher stores 1 if the kernel it would pick for this shape can write yn (else 0) and does not launch
-    int no_direct;         // 1: statistics through the LDS column pass even where the epilogue could take them from the accumulators (WDM_EPI_DIRECT=0)
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
                            //    (plain GEMMs over M rows that do not fill the last row of the 16-wide pixel grid)
@@ -607,105 +606,158 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
     }
 }
 
-template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
+// ------------------------------------------------------------------------------------------------
+// epilogue, packed form: bf16 NHWC outputs WITHOUT a residual operand (conv1 of every ResnetBlock, conv2 with the fused 1x1 shortcut, conv_in, Up /
+// Downsample) on 16-wide pixel tiles, wave tile = 64 rows x 64 columns per pass.
+// The fp32 form above moves every output through LDS three times in fp32 (accumulators in: 16 ds_write_b128 per lane, the rounded values back for the
+// statistics: 16 more, the column pass) -- and ds_write_b128 runs at ~79 B/clk/CU: ~3.3 k of a 256 x 128 tile's ~8 k epilogue ticks are those two store
+// phases.  Without a residual nothing needs the row layout in fp32: alpha * acc + (bias + shortcut bias + temb) is formed and rounded in the ACCUMULATOR
+// layout (a lane holds 4 consecutive channels of a pixel: the additive terms are 4 floats per fragment column), the tile goes to LDS once, as bf16 (8 KB per
+// wave instead of 17), the row loop only moves 16-byte units LDS -> HBM, and the column pass (lane = channel, rows in the same chunk order) reads the
+// rounded values -- the same operations on the same numbers as the fp32 form, so outputs and statistics are bit-identical to it.
+// LDS tile: row r = 128 bytes = eight 16-byte units; unit u sits in slot u ^ (r & 7) and its two 8-byte halves are swapped when r & 8 -- the 16 pixel
+// lanes of a ds_write_b64 then cover all 32 banks, the 2 x 8 lanes of a ds_read_b128 service group cover all 64, and the swap is a compile-time register
+// order in the row loop (rows of iteration `it` have (r >> 3) & 1 == it & 1).
+// `hook()` runs when the row loop's stores are issued (first pass only).
+// ------------------------------------------------------------------------------------------------
+template <class AT>
+__host__ __device__ __forceinline__ bool conv_epilogue_can_pack(const AT& a) {
+#ifdef WDM_NO_PACK          // tools: A/B against the fp32 form
+    return false;
+#else
+    return a.res == nullptr && a.y_mode == Y_NHWC && (a.Cout % 8) == 0 && a.m_valid == 0;
+#endif
+}
+constexpr int EPI_PACK_TILE = 64 * 128;      // LDS bytes per wave
+template <int TH, int TW, int WN, class Hook = EpiNoHook, class AT = ConvArgs>
+__device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4][WN], int jp, char* smem, int wave, int lane_, int wave_m, int wave_n, int img0, int oy0,
+                                                     int ox0, int n0, int tile_in_img, int phase, Hook hook, bool call_hook) {
+    constexpr int EROWS = 64, ROWB = 128;
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));             // every address below is a function of the lane: formed HERE, not hoisted above the K loop (where ~40 of them would
+                                               // stay live through it and spill the accumulators of the 256-column tiles)
+    char* const tp = smem + wave * EPI_PACK_TILE;
+    const int quad = lane >> 4, px = lane & 15;
+    const int ncol0 = n0 + (wave_n * WN + jp) * 16;            // first channel of this pass
+    if (jp != 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }       // the previous pass's column reads (same wave: LDS in order)
+    __builtin_amdgcn_sched_barrier(0);            // a pass's loads stay inside the pass (hoisted across passes they spill the accumulators of 256-column tiles)
+    // ---- final values in the accumulator layout -> bf16 tile
+    {
+        const int img_w = img0 + (wave_m * EROWS) / (TH * TW);
+        const long long trow = (a.temb != nullptr && a.temb_per_image) ? (img_w < a.B ? img_w : a.B - 1) : 0;
+        const int wr0 = px * ROWB + (((quad & 1) ^ (px >> 3)) << 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol0 + j * 16 + quad * 4;
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < a.Cout) {                 // the order of conv_epilogue_w: bias, + shortcut bias, + temb
+                if (a.bias != nullptr) ad = *(const float4*)(a.bias + n);
+                if (a.sbias != nullptr) { const float4 c = *(const float4*)(a.sbias + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
+                if (a.temb != nullptr) { const float4 c = *(const float4*)(a.temb + trow * a.temb_ld + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
+            }
+            const int wr = wr0 + (((j * 2 + (quad >> 1)) ^ (px & 7)) << 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = acc[i][jp + j];
+                uint2 pk;
+                pk.x = TI<__bf16>::pack2(__builtin_fmaf(v[0], a.alpha, ad.x), __builtin_fmaf(v[1], a.alpha, ad.y));
+                pk.y = TI<__bf16>::pack2(__builtin_fmaf(v[2], a.alpha, ad.z), __builtin_fmaf(v[3], a.alpha, ad.w));
+                *(uint2*)(tp + wr + i * (16 * ROWB)) = pk;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- row loop: a lane moves 8 consecutive channels (one 16-byte unit) of a pixel, 8 rows per iteration (conv_epilogue_w's addresses for NJ = 4)
+    {
+        constexpr unsigned OOBV = 0xFFFF0000u;
+        const long long out_rows = a.up4 ? (long long)a.B * 4 * a.Hout * a.Wout : (long long)a.B * a.Hout * a.Wout;
+        const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(unsigned)(out_rows * a.y_s * 2), 0x00020000);
+        const int c8 = (lane & 7) * 8, lp = lane >> 3;
+        const int n = ncol0 + c8;
+        const int lane_pix = !a.up4 ? lp : lp * 2;                      // lp < 8 <= TW: the lane's row of an iteration lies in one image row
+        const unsigned vo_y = n < a.Cout ? (unsigned)((lane_pix * a.y_s + n) * 2) : OOBV;
+        const int rd = lp * ROWB + (((lane & 7) ^ lp) << 4);
+        uint4 tl[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) tl[it] = *(const uint4*)(tp + rd + it * (8 * ROWB));
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mu = wave_m * EROWS + it * 8;                     // wave-uniform
+            const int img_u = mu / (TH * TW), rru = mu % (TH * TW);
+            const int oyu = oy0 + rru / TW, oxu = ox0 + rru % TW;
+            const int img_g = img0 + img_u;
+            if (img_g >= a.B) continue;
+            const int so_pix = !a.up4 ? (img_g * a.Hout + oyu) * a.Wout + oxu
+                                      : (img_g * (2 * a.Hout) + 2 * oyu + (phase >> 1)) * (2 * a.Wout) + 2 * oxu + (phase & 1);
+            const unsigned vst = vo_y == OOBV ? OOBV : vo_y + (unsigned)so_pix * (unsigned)a.y_s * 2u;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 pk = (it & 1) ? u32x4{tl[it].z, tl[it].w, tl[it].x, tl[it].y} : u32x4{tl[it].x, tl[it].y, tl[it].z, tl[it].w};
+            if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(pk, r_y, (int)vst, 0, 0);
+        }
+    }
+    if (call_hook) hook();
+    // ---- GroupNorm partial statistics of the values as stored: lane = channel, 64 rows in four 16-row chunks (the association of conv_epilogue_w's
+    // one-pass form); group-level partials as there
+    if (a.stats != nullptr) {
+        const int col = lane, u = col >> 3, e = col & 7;
+        int va[2][8];                                   // [(r >> 3) & 1][r & 7]: byte offset of this channel inside row r
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[h][k] = ((u ^ k) << 4) | ((((e >> 2) ^ h)) << 3) | ((e & 3) << 1);
+        auto val = [&](int r) __attribute__((always_inline)) {
+            return __uint_as_float((unsigned)*(const unsigned short*)(tp + r * ROWB + va[(r >> 3) & 1][r & 7]) << 16);
+        };
+        const float K = val(0);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = val(ch * 16 + r) - K; c1 += d; c2 = __builtin_fmaf(d, d, c2); }
+            if (ch == 0) { s1 = c1; s2 = c2; } else { s1 += c1; s2 += c2; }
+            __builtin_amdgcn_sched_barrier(0);          // one chunk's 16 reads in flight at a time (all 64 hoisted cost more registers than the kernels have)
+        }
+        const int m0 = wave_m * EROWS;
+        const int img_g = img0 + m0 / (TH * TW);
+        constexpr int SPT = (TH * TW) / 64;
+        const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / 64 + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
+        const int nn = ncol0 + col;
+        if (nn < a.Cout && img_g < a.B) ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, 64.f);
+        if (a.gst != nullptr) {
+            const int gs = a.Cout >> 5;
+            const float Kg = __shfl(K, lane & ~(gs - 1));
+            const float d = K - Kg, nr = 64.f;
+            float g1 = __builtin_fmaf(nr, d, s1);
+            float g2 = __builtin_fmaf(nr * d, d, __builtin_fmaf(2.0f * d, s1, s2));
+            for (int off = 1; off < gs; off <<= 1) { g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
+            if ((lane & (gs - 1)) == 0 && nn < a.Cout && img_g < a.B) {
+                float* q = a.gst + (((long long)img_g * a.stats_nslab + slab) * 32 + nn / gs) * 3;
+                q[0] = Kg; q[1] = g1; q[2] = g2;
+            }
+        }
+    }
+}
+
+template <typename T, int TH, int TW, int WM, int WN, int NJ_ = 0, class Hook = EpiNoHook, bool CANON = false, int PACK = 0, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN], char* smem, bool active, int wave, int lane, int wave_m,
                                               int wave_n, int img0, int oy0, int ox0, int n0, int tile_in_img, int phase = 0, Hook hook = Hook(),
                                               bool entry_barrier = true, float4* keep_tab = nullptr, int keep_bn = 0) {
     if (WDM_EABL & 2) { float t = 0.f; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 123.456f) ((float*)a.y)[0] = t; return; }
     constexpr int NJ = NJ_ ? NJ_ : ((WN >= 2) ? 2 : 1);
     constexpr int ESTR = 16 * NJ + 4;
-    // ---- direct path (convs WITHOUT a residual operand that emit statistics: conv1 of every ResnetBlock, conv2 with the fused shortcut, Down / Upsample,
-    // conv_in): the final values alpha * acc + bias + temb are formed in the accumulator layout -- a lane holds 4 consecutive channels of one pixel --,
-    // and the GroupNorm partial statistics come straight from them: per slab the pivot is the value of the slab's first pixel, a lane sums its fragments'
-    // rows, a fixed xor tree joins the 16 pixel lanes.  The LDS tile then carries final values and the row loop only rounds and stores: no write-back of
-    // the rounded values, no column pass over the tile (of the 7.7 k ticks of a 256 x 128 tile's epilogue the column pass was 2.4 k, the write-back ~0.6 k).
-    // Convs with a residual need the row layout for its 16-byte loads and keep the column pass.
-    // MEASURED (round 3): -3.5 % end to end (576 / 582 vs 600 / 601 img/s at 20 steps; -4.3 % with ds_bpermute shuffles instead of the DPP rotations): in the
-    // column pass a lane IS a channel -- 64 independent LDS reads and three VALU per row, no cross-lane step --, here every value costs a rounding round trip
-    // and every channel a 16-lane reduction.  Off by default (WDM_EPI_DIRECT=1); every test passes with it on.
-    constexpr int EROWS_ = 16 * WM;
-    constexpr bool ONE_IMG_ = (TH * TW) % EROWS_ == 0;
-    constexpr int SROWS_ = conv_stat_rows(TH, TW, EROWS_);
-    bool direct = false;
-    if constexpr (ONE_IMG_ && SROWS_ % 16 == 0 && EROWS_ % SROWS_ == 0) {
-        direct = active && !a.no_direct && keep_tab == nullptr && a.stats != nullptr && a.res == nullptr && a.m_valid == 0 && (a.y_mode == Y_NHWC || a.y_mode == Y_NHWC_F32) && (a.Cout % 8 == 0);
-        if (direct) {
-            constexpr int FPS = SROWS_ / 16, NSL = EROWS_ / SROWS_, SPT = (TH * TW) / SROWS_;
-            const int img_w = img0 + (wave_m * EROWS_) / (TH * TW);
-            const long long trow = (a.temb != nullptr && a.temb_per_image) ? (img_w < a.B ? img_w : a.B - 1) : 0;
-            const int gs = a.Cout >> 5;
-            const int quad = lane >> 4;
+    // (Round 3's "direct" form -- final values and GroupNorm statistics taken in the accumulator layout, 16-lane DPP reductions per channel -- measured
+    // 3.5 % slower end to end and is gone; conv_epilogue_packed below keeps the column pass and drops the fp32 round trips instead.)
+    // PACK = 1: the packed form when the arguments allow it (run-time test), 2: always (the launcher has tested: no fp32 form in the kernel at all)
+    if constexpr (PACK != 0) {
+        static_assert(TI<T>::VEC == 8 && WM == 4 && (WN % 4) == 0 && TW == 16 && (TH * TW) % 64 == 0, "packed epilogue: bf16, 64-row wave tiles of a 16-wide pixel tile");
+        if (PACK == 2 || (keep_tab == nullptr && conv_epilogue_can_pack(a))) {
+            if (entry_barrier) __syncthreads();
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int n = n0 + (wave_n * WN + j) * 16 + quad * 4;                  // this lane's 4 consecutive channels of fragment column j
-                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < a.Cout) {
-                    if (a.bias != nullptr) ad = *(const float4*)(a.bias + n);
-                    if (a.sbias != nullptr) { const float4 c = *(const float4*)(a.sbias + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
-                    if (a.temb != nullptr) { const float4 c = *(const float4*)(a.temb + trow * a.temb_ld + n); ad.x += c.x; ad.y += c.y; ad.z += c.z; ad.w += c.w; }
-                }
-                const float add[4] = {ad.x, ad.y, ad.z, ad.w};
-                float vr[WM][4];                                                       // the values as the consumer will read them back
-#pragma unroll
-                for (int i = 0; i < WM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], a.alpha, add[r]);
-                    if (a.y_mode == Y_NHWC && TI<T>::VEC == 8) {
-                        const unsigned p0 = TI<__bf16>::pack2(acc[i][j][0], acc[i][j][1]), p1 = TI<__bf16>::pack2(acc[i][j][2], acc[i][j][3]);
-                        vr[i][0] = __uint_as_float(p0 << 16); vr[i][1] = __uint_as_float(p0 & 0xffff0000u);
-                        vr[i][2] = __uint_as_float(p1 << 16); vr[i][3] = __uint_as_float(p1 & 0xffff0000u);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vr[i][r] = acc[i][j][r];
-                    }
-                }
-#pragma unroll
-                for (int sl = 0; sl < NSL; ++sl) {
-                    float K[4], s1[4], s2[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        K[r] = __shfl(vr[sl * FPS][r], lane & 48);                      // the slab's first pixel (pixel lane 0 of its first fragment)
-#pragma unroll
-                        for (int f = 0; f < FPS; ++f) {
-                            const float d = vr[sl * FPS + f][r] - K[r];
-                            if (f == 0) { s1[r] = d; s2[r] = d * d; } else { s1[r] += d; s2[r] = __builtin_fmaf(d, d, s2[r]); }
-                        }
-                        // all-reduce over the 16 pixel lanes of the row by DPP rotations (one VALU each; __shfl_xor is a ds_bpermute round trip: measured
-                        // -4 % end to end in the first version of this path); only pixel lane 0's total is used, so the order is fixed
-                        s1[r] += dpp_row_ror<1>(s1[r]); s2[r] += dpp_row_ror<1>(s2[r]);
-                        s1[r] += dpp_row_ror<2>(s1[r]); s2[r] += dpp_row_ror<2>(s2[r]);
-                        s1[r] += dpp_row_ror<4>(s1[r]); s2[r] += dpp_row_ror<4>(s2[r]);
-                        s1[r] += dpp_row_ror<8>(s1[r]); s2[r] += dpp_row_ror<8>(s2[r]);
-                    }
-                    const int m0 = wave_m * EROWS_ + sl * SROWS_;
-                    const int img_g = img0 + m0 / (TH * TW);
-                    const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS_ + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
-                    const bool wr = (lane & 15) == 0 && n < a.Cout && img_g < a.B;
-                    if (wr) {
-                        float4* q = (float4*)a.stats + ((long long)img_g * a.stats_nslab + slab) * a.Cout + n;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) q[r] = make_float4(K[r], s1[r], s2[r], (float)SROWS_);
-                    }
-                    if (a.gst != nullptr) {
-                        // group-level partials (gn_inline.h): a group's gs = 4 / 8 / 16 channels are this lane's four and those of 1 / 2 / 4 quadrant lanes
-                        const float Kg = __shfl(K[0], (lane & 15) | ((quad & ~((gs >> 2) - 1)) << 4));
-                        const float nr = (float)SROWS_;
-                        float g1 = 0.f, g2 = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float d = K[r] - Kg;
-                            const float t1 = __builtin_fmaf(nr, d, s1[r]), t2 = __builtin_fmaf(nr * d, d, __builtin_fmaf(2.0f * d, s1[r], s2[r]));
-                            if (r == 0) { g1 = t1; g2 = t2; } else { g1 += t1; g2 += t2; }
-                        }
-                        if (gs >= 8) { g1 += __shfl_xor(g1, 16); g2 += __shfl_xor(g2, 16); }
-                        if (gs >= 16) { g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32); }
-                        if (wr && (quad & ((gs >> 2) - 1)) == 0) {
-                            float* q = a.gst + (((long long)img_g * a.stats_nslab + slab) * 32 + n / gs) * 3;
-                            q[0] = Kg; q[1] = g1; q[2] = g2;
-                        }
-                    }
-                }
-            }
+            for (int jp = 0; jp < WN; jp += 4)
+                conv_epilogue_packed<TH, TW, WN, Hook, AT>(a, acc, jp, smem, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, jp == 0);
+            return;
         }
     }
     auto write_pass = [&](float* ep, int jp) __attribute__((always_inline)) {      // [channel][pixel] fragments -> ep[pixel][channel]
@@ -716,7 +768,7 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
                 *(float4*)(ep + (i * 16 + (lane & 15)) * ESTR + jj * 16 + (lane >> 4) * 4) = make_float4(acc[i][jp + jj][0], acc[i][jp + jj][1], acc[i][jp + jj][2], acc[i][jp + jj][3]);
     };
     conv_epilogue_w<T, TH, TW, WM, WN, NJ_, decltype(write_pass)&, Hook, CANON>(a, write_pass, smem, active, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, entry_barrier,
-                                                                                direct, keep_tab, keep_bn);
+                                                                                false, keep_tab, keep_bn);
     WDM_ETS(5);
 #ifdef WDM_EPI_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
