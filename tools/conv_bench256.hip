@@ -54,7 +54,8 @@ int main(int argc, char** argv) {
         {"t256x256F", conv_dma256_kernel<4, 2, 4, 8, 16, false>, C256::LDS_BYTES, 16, 256, 0},
         {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
         {"persistF", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
-        {"two80", conv_dma2_kernel, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
+        {"two80", conv_dma2_kernel<true>, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
+        {"two80F", conv_dma2_kernel<false>, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
     };
     if (getenv("ONLY")) { std::vector<Variant> keep = {vars[0]}; for (size_t i = 1; i < vars.size(); ++i) if (strstr(getenv("ONLY"), vars[i].name)) keep.push_back(vars[i]); vars = keep; }
     const int NCU = getenv("NCU") ? atoi(getenv("NCU")) : 256;
@@ -123,7 +124,7 @@ int main(int argc, char** argv) {
             if (vars[i].persist && grid[i] > NCU) grid[i] = NCU;
         }
         std::vector<int> skip(NV, 0);
-        for (int v = 0; v < NV; ++v) skip[v] = (vars[v].bn == 256 && Cout % 256 != 0) || (!strcmp(vars[v].name, "two80") && (sh.sc != 0 || Cin > 1024))
+        for (int v = 0; v < NV; ++v) skip[v] = (vars[v].bn == 256 && Cout % 256 != 0) || (!strncmp(vars[v].name, "two80", 5) && (sh.sc != 0 || Cin > 1024)) || (!strcmp(vars[v].name, "two80") && sh.res) || (!strcmp(vars[v].name, "two80F") && !sh.res)
 #ifdef WDM_NO_PACK
             || !strcmp(vars[v].name, "persist1") || !strcmp(vars[v].name, "t256x256");
 #else

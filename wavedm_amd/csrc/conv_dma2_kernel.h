@@ -28,6 +28,7 @@ struct ConvDma2Cfg {
     static_assert(EPI_BYTES <= LDS_BYTES && 3 * G_STAGE <= LDS_BYTES && LDS_BYTES <= 80 * 1024, "LDS");
 };
 
+template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void conv_dma2_kernel(const ConvArgs a) {
     using C = ConvDma2Cfg;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma2_kernel(const ConvArgs a) {
     // a wave's 128 rows = wave rows 2 wave_m and 2 wave_m + 1 of the eight-wave kernels: two one-pass epilogues through the same 64 x 68 LDS tile
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-        conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, 1>(a, *(f32x4 (*)[4][WN])&acc[4 * p], smem, true, wave, lane, wave_m * 2 + p, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), false);
+        conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, (PACKED ? 2 : 0)>(a, *(f32x4 (*)[4][WN])&acc[4 * p], smem, true, wave, lane, wave_m * 2 + p, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), false);
 }
 
 }  // namespace wdm

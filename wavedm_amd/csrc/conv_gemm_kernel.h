@@ -191,7 +191,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid,
         return;
     }
     // 8 x 8 maps (four images per tile): half-image statistics slabs need the two-fragment passes (conv_stat_rows)
-    conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : C::EPI_NJ)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : C::EPI_NJ), EpiNoHook, false, ((TH * TW) % 64 == 0 && TW == 16 && WM == 4 && WN % 4 == 0 && TH * TW != 64 ? 1 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // CANON: the two-pass epilogue of the 64-column tile sums a slab's statistics in the order of the one-pass one (conv_kernel.h) -- both N tiles, same bits
-    conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ, EpiNoHook, true>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
+    conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ, EpiNoHook, true, ((TH == 16 && WN == 4) ? 1 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
 }  // namespace wdm

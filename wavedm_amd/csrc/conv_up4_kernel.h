@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
 #undef WDM_UP4_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
+    conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ, EpiNoHook, false, (TH == 16 ? 1 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
 }
 
 }  // namespace wdm
