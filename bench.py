@@ -338,6 +338,57 @@ def main():
         d.args = a
         log(f"[bench] extra configs[4]: {8 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per 8 images)")
         del rest4, loader4
+        # configs[4] through the WHOLE restore() pipeline: PNG files on disk -> wavedm_amd.datasets.RainDrop loader (PIL decode +
+        # LANCZOS resizes, pinned DataLoader) -> device HFRM with procedural weights (models/arch.py, once per image) -> DWT -> stitched 50-step sampler ->
+        # IDWT -> three PSNRs on the device -> 8-bit conversion on the device + seven PNGs per image through the asynchronous writer (flushed inside the clock)
+        try:
+            import tempfile, shutil, copy
+            import numpy as np
+            from PIL import Image
+            from wavedm_amd.datasets import RainDrop
+            root = tempfile.mkdtemp(prefix="wdm_c4_")
+            rng = np.random.default_rng(44)
+            for sub_ in ("raindrop_test", "train"):
+                for leaf in ("input", "gt"):
+                    os.makedirs(os.path.join(root, "raindrop", sub_, leaf))
+            for k in range(8):
+                clean = rng.integers(0, 256, (480, 720, 3), dtype=np.uint8)
+                drop = np.clip(clean.astype(np.int16) + rng.integers(-40, 41, (480, 720, 3)), 0, 255).astype(np.uint8)
+                Image.fromarray(drop).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
+                Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
+            cfg4 = copy.deepcopy(cfg)
+            cfg4.device = dev
+            cfg4.data.data_dir = root
+            cfg4.data.num_workers = 4
+            a5 = SimpleNamespace(**vars(a))
+            a5.sampling_timesteps, a5.images_per_call, a5.max_batch, a5.world_size, a5.rank = 50, 8, 128, 1, 0
+            a5.image_folder = os.path.join(root, "out")
+            d.args = a5
+            ident = d.generator
+            d.generator = d._make_generator("procedural", args.dtype)
+            rest5 = wavedm_amd.DiffusiveRestoration(d, a5, cfg4, save_images=True)
+
+            def pass_c4_real():
+                with contextlib.redirect_stdout(io.StringIO()):
+                    _, val_loader = RainDrop(a5, cfg4).get_loaders(parse_patches=False, validation="raindrop")
+                    rest5.restore(val_loader, validation="raindrop", r=16)          # ends with writer.flush(): every PNG is on disk
+            t5 = timed(pass_c4_real)
+            n_png = len(os.listdir(os.path.join(a5.image_folder, cfg4.data.dataset, "raindrop")))
+            extras.append({"workload": "BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: 8 PNG pairs on disk -> RainDrop loader (PIL, 4 workers) -> device HFRM "
+                                       "(procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, 50 DDIM steps, 8 images per sampler call -> "
+                                       "IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
+                           "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 1, "warmup": 1, "pngs_written": n_png,
+                           "vs_identity_standin_leg": round(t4 / t5, 3)})
+            log(f"[bench] extra configs[4] whole pipeline (real HFRM, loader, PNGs): {8 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per 8 images, {n_png} PNGs)")
+            rest5.writer.close()
+            d.generator = ident
+            d.args = a
+            del rest5
+            shutil.rmtree(root, ignore_errors=True)
+        except Exception as e:                                      # the informational leg must not take the headline down with it
+            log(f"[bench] extra configs[4] whole pipeline FAILED: {type(e).__name__}: {e}")
+            extras.append({"workload": "BASELINE.json configs[4] whole restore() pipeline", "value": None, "error": f"{type(e).__name__}: {e}"})
+            d.args = a
         # configs[2]: 128x128 wavelet-domain patches, batch 256, 100 steps (its own 163 M-parameter UNet: attention sits one level deeper)
         cfg2 = P.raindrop_wavelet_config(image_size=128)
         cfg2.device = dev
@@ -362,18 +413,56 @@ def main():
         # as three bf16 MFMAs on hi/lo-split operands; "f32" (exact): v_mfma_f32_16x16x4_f32 chains, bit-for-bit fp32 FMA order.
         def rel(u, v):
             return float((u.double() - v.double()).abs().max() / v.double().abs().max())
-        rp, xp = P.synthetic_batch(B, patch_px=256, seed=63)
-        rp, xp = rp.to(dev), xp.to(dev)
         a.sampling_timesteps = 10
         modes = {}
         headline_rel = None
         for name in ("f32x3", "f32"):
             df = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=name)
             df.model.load_state_dict(sd, strict=True)
-            tp_ = timed(lambda: df.restore_batch(rp, xp))
-            ips = B / (tp_ * args.ddim_steps / 10)
-            m = {"dtype": name, "value": round(ips, 3), "unit": "img/s",
-                 "sample": f"{B} crops x 10 DDIM steps = {tp_ * 1e3:.0f} ms, scaled x{args.ddim_steps // 10} to {args.ddim_steps} steps", "tolerance": 1e-3}
+            if name == "f32x3":
+                # the tolerance-conformant mode as a first-class number: the SAME 64 crops as the headline, ALL ddim steps,
+                # 1 warm-up pass + 3 timed passes, and its own roofline leg (events around every conv launch of one more pass)
+                a.sampling_timesteps = args.ddim_steps
+                df.restore_batch(rainy, x_T)
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                for _ in range(3):
+                    df.restore_batch(rainy, x_T)
+                torch.cuda.synchronize()
+                tp_ = (time.perf_counter() - tq) / 3
+                ips = B / tp_
+                m = {"dtype": name, "value": round(ips, 3), "unit": "img/s", "ms_per_step": round(tp_ * 1e3, 2), "steps": args.ddim_steps, "passes": 3, "warmup": 1,
+                     "sample": f"the headline's {B} crops, all {args.ddim_steps} DDIM steps, mean of 3 passes after 1 warm-up pass", "tolerance": 1e-3}
+                _lib.prof_enable(True)
+                df.restore_batch(rainy, x_T)
+                torch.cuda.synchronize()
+                sh3 = [e for e in _lib.prof_report() if e["flops"] > 0]
+                _lib.prof_enable(False)
+                agg3 = {}
+                for e in sh3:
+                    k = e["kernel"].split("|")[0]
+                    r_ = agg3.setdefault(k, dict(kernel=k, launches=0, ms=0.0, flops=0.0))
+                    for f in ("launches", "ms", "flops"):
+                        r_[f] += e[f]
+                rep3 = sorted(agg3.values(), key=lambda e: -e["ms"])
+                tot3 = sum(e["ms"] for e in rep3)
+                for e in rep3[:8]:
+                    log(f"[bench] f32x3 {e['kernel']:<40s} launches {e['launches']:6d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  {100 * e['ms'] / tot3:5.1f}%")
+                d3 = rep3[0]
+                # one fp32 product = two full-rate bf16 MFMAs with the split operands, four times the MFMA time of a bf16 product: 2500 / 4
+                pk3 = MFMA_BF16_PEAK_TFLOPS / 4
+                m["roofline"] = {"bound": "mfma", "kernel": d3["kernel"], "launches": d3["launches"], "avg_launch_us": round(d3["ms"] / d3["launches"] * 1e3, 2),
+                                 "achieved": round(d3["flops"] / d3["ms"] / 1e9, 2), "peak": pk3, "unit": "TFLOP/s (fp32-equivalent: 2 M N K per product)",
+                                 "frac": round(d3["flops"] / d3["ms"] / 1e9 / pk3, 4), "all_conv_tflops": round(sum(e["flops"] for e in rep3) / tot3 / 1e9, 2),
+                                 "conv_ms_per_pass": round(tot3, 2), "profile": "profiles/r04_kernel_stats_f32x3.md"}
+                a.sampling_timesteps = 10
+            else:
+                rp, xp = P.synthetic_batch(B, patch_px=256, seed=63)
+                rp, xp = rp.to(dev), xp.to(dev)
+                tp_ = timed(lambda: df.restore_batch(rp, xp))
+                ips = B / (tp_ * args.ddim_steps / 10)
+                m = {"dtype": name, "value": round(ips, 3), "unit": "img/s",
+                     "sample": f"{B} crops x 10 DDIM steps = {tp_ * 1e3:.0f} ms, scaled x{args.ddim_steps // 10} to {args.ddim_steps} steps", "tolerance": 1e-3}
             if cpu_sample is not None:
                 _, xl, x0g = df.restore_batch(cpu_sample["rainy"].to(dev), cpu_sample["x_T"].to(dev))
                 m["rel_linf_vs_oracle"] = float(f"{max(rel(xl.cpu(), cpu_sample['xs_last']), rel(x0g.cpu(), cpu_sample['x0_m5'])):.3e}")

@@ -213,6 +213,59 @@ def test_config2_r128_forward():
         torch.cuda.empty_cache()
 
 
+def test_config2_r128_sampler():
+    """BASELINE.json configs[2] at SAMPLER level: 2 crops of 512x512 px -> 128x128 wavelet domain, 10 DDIM steps through
+    restore_batch (DWT, the 163 M-parameter UNet with its N = 256 / d = 768 attention inside the loop -- models/unet.py:168-193, resolution
+    assert :346-351 --, DDIM update, IDWT) against the CPU oracle's trajectory: xs[-1] and x0_preds[-5], f32 / f32x3 <= 1e-3, bf16 <= its bound."""
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import procedural as P
+    cfg = P.raindrop_wavelet_config(image_size=128)
+    sd = P.procedural_state_dict(cfg)
+    rainy, x_T = P.synthetic_batch(2, patch_px=512, seed=77)
+    assert x_T.shape == (2, 3, 128, 128)
+    xc = O.dwt_fwd(2 * rainy - 1)
+    oxs, ox0 = O.ddim_batch(sd, cfg, x_T, xc, xc[:, 3:].contiguous(), 10, chunk=2)
+    for dtype in ("f32", "f32x3", "bf16"):
+        d, _ = make_diffusion(P.raindrop_wavelet_config(image_size=128), dtype, 10)
+        out, xs_last, x0m5 = d.restore_batch(rainy.cuda(), x_T.cuda())
+        e1, e2 = rel_linf(xs_last.cpu(), oxs[-1]), rel_linf(x0m5.cpu(), ox0[-5])
+        print(f"config2 R=128 sampler {dtype}: rel_linf xs[-1] {e1:.3e}, x0_preds[-5] {e2:.3e}")
+        assert e1 <= TOL[dtype] and e2 <= TOL[dtype]
+        assert out.shape == (2, 3, 512, 512) and bool(torch.isfinite(out).all())
+        del d
+        torch.cuda.empty_cache()
+
+
+def test_config2_b256_properties_bf16():
+    """configs[2]'s full batch (256 patches of 128x128, bf16): the tile rules count workgroups, so what a batch of 2 exercises is not what a batch of
+    256 runs (the B >= 100 rule of round 3 was such a case).  One UNet call at B = 256 twice (determinism), images 100-107 alone (an image's bits do
+    not depend on the batch it sits in), finiteness; then 3 DDIM steps of all 256 through the sampler against the same 8 crops alone."""
+    import wavedm_amd
+    from wavedm_amd import procedural as P
+    cfg = P.raindrop_wavelet_config(image_size=128)
+    net = build(cfg, "bf16")
+    x = seeded((256, 96, 128, 128), 123).cuda()
+    t = torch.tensor([610.0])
+    a = net(x, t)
+    b = net(x, t)
+    assert a.shape == (256, 3, 128, 128) and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b)
+    c = net(x[100:108].contiguous(), t)
+    assert torch.equal(a[100:108], c)
+    del a, b, c, x, net
+    torch.cuda.empty_cache()
+    d, args = make_diffusion(P.raindrop_wavelet_config(image_size=128), "bf16", 3)
+    rainy, x_T = P.synthetic_batch(256, patch_px=512, seed=78)
+    rainy, x_T = rainy.cuda(), x_T.cuda()
+    for mb in (64, 256):                                     # the bench's chunking, and one 256-patch UNet call per step
+        args.max_batch = mb
+        out, xs_last, x0 = d.restore_batch(rainy, x_T, keep=-1)
+        assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(xs_last).all())
+        o8, xs8, x08 = d.restore_batch(rainy[100:108].contiguous(), x_T[100:108].contiguous(), keep=-1)
+        assert torch.equal(xs_last[100:108], xs8) and torch.equal(x0[100:108], x08) and torch.equal(out[100:108], o8)
+        del out, xs_last, x0
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
 def test_config4_fullres_stitch(dtype):
     """BASELINE.json configs[4] geometry: one 480x720 image -> 120x180 wavelet domain -> 45 overlapping 64x64 patches

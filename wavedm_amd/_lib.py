@@ -160,9 +160,19 @@ def set_concurrent_streams(n: int):
     check(lib().wdm_set_concurrent_streams(int(n)))
 
 
+_ENV_GEN = 0
+
+
 def env_refresh():
-    """Have the library re-read its WDM_* experiment switches (they are read once, at first use)."""
+    """Have the library re-read its WDM_* experiment switches (they are read once, at first use).  Switches change the size of the activation arena,
+    so every cached workspace is stale afterwards: the generation counter makes DiffusionUNet.workspace() re-query and re-allocate."""
+    global _ENV_GEN
     check(lib().wdm_env_refresh())
+    _ENV_GEN += 1
+
+
+def env_generation() -> int:
+    return _ENV_GEN
 
 
 def prof_report():

@@ -124,10 +124,41 @@ __global__ __launch_bounds__(256) void pack_channels_kernel(const float* __restr
     }
 }
 
+// The same gather with coalesced accesses on BOTH sides (the kernel above reads NCHW with the channel as the fastest thread index: lanes H W floats apart).
+// One workgroup per (patch, patch row): the row's nch x p values are read channel by channel -- consecutive lanes = consecutive pixels of one channel
+// plane --, turned in LDS (row stride p + 1 floats: odd, conflict-free both ways) and written pixel by pixel, channels fastest, as the NHWC row wants them.
+constexpr int PACK_MAX_P = 128, PACK_MAX_CH = 48;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_channels_rows_kernel(const float* __restrict__ src, int nch, int H, int W, const int32_t* __restrict__ patches,
+                                                                 int p, T* __restrict__ x96, int c_total, int c_off) {
+    __shared__ float tile[PACK_MAX_CH * (PACK_MAX_P + 1)];
+    const int k = (int)(blockIdx.x / (unsigned)p), yy = (int)(blockIdx.x - (unsigned)k * (unsigned)p);
+    int img = k, hi = 0, wi = 0;
+    if (patches != nullptr) { img = patches[3 * k]; hi = patches[3 * k + 1]; wi = patches[3 * k + 2]; }
+    const int ld = p + 1, tot = nch * p;
+    const float* row0 = src + ((long long)img * nch * H + hi + yy) * W + wi;
+    for (int id = threadIdx.x; id < tot; id += 256) {
+        const int c = id / p, xx = id - c * p;
+        tile[c * ld + xx] = row0[(long long)c * H * W + xx];
+    }
+    __syncthreads();
+    T* out = x96 + ((long long)k * p + yy) * p * c_total + c_off;
+    for (int id = threadIdx.x; id < tot; id += 256) {
+        const int xx = id / nch, c = id - xx * nch;
+        TI<T>::st(out, (long long)xx * c_total + c, tile[c * ld + xx]);
+    }
+}
+
 int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96, int c_total, int c_off, int dtype,
                     hipStream_t s) {
     if (n <= 0 || p <= 0 || nch <= 0 || c_off < 0 || c_off + nch > c_total) WDM_FAIL(WDM_EINVAL, "pack_channels: bad arguments");
     if (patches == nullptr && (p != H || p != W)) WDM_FAIL(WDM_EINVAL, "pack_channels: identity patch list needs p == H == W");
+    if (p <= PACK_MAX_P && nch <= PACK_MAX_CH && (long long)n * p < 2147483647LL) {
+        if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_channels_rows_kernel<__bf16>, dim3(n * p), dim3(256), 0, s, src, nch, H, W, patches, p, (__bf16*)x96, c_total, c_off);
+        else hipLaunchKernelGGL(pack_channels_rows_kernel<float>, dim3(n * p), dim3(256), 0, s, src, nch, H, W, patches, p, (float*)x96, c_total, c_off);
+        WDM_HIP(hipGetLastError());
+        return WDM_OK;
+    }
     const long long total = (long long)n * p * p * nch;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
     if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_channels_kernel<__bf16>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (__bf16*)x96, c_total, c_off);

@@ -204,8 +204,8 @@ class DenoisingDiffusion_Wavelet(object):
         if patch_locs is None:
             # ddm_wavelet.py:305-306 falls through to utils.sampling.generalized_steps (utils/sampling.py:23-44): every image is ONE patch of the
             # model's resolution and the UNet sees [x_cond | x_t] (its conv_in must be built for that width: model.use_other_channels False)
-            if not self.config.data.begin_from_noise:
-                pass                                                            # generalized_steps starts from x as given (no q-sample of x_cond)
+            # (generalized_steps starts from x as given whatever data.begin_from_noise says: there is no q-sample of x_cond on this path)
+            self._require_plain_unet("sample_image(patch_locs=None)")
             xs = sampling.ddim_sample(self.model, x, x_cond, None, list(seq), self.betas, corners=None, max_batch=getattr(self.args, "max_batch", 64))
             return xs[0][-1] if last else xs
         xs = self.generalized_steps_overlapping(x, x_cond, seq, self.model, self.betas, eta=0., corners=patch_locs,

@@ -163,25 +163,25 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                 sc = pool[ci]
                 sc.wait_stream(main)                                  # inputs, x96's constant channels and the temb table are ready
                 chunks.append((lo, min(lo + per, n), sc))
-            for ci, (lo, hi, _) in enumerate(chunks):                # the chunks' workspaces, allocated here on the caller's stream
-                for i in range(lo, hi, max_batch):
-                    unet.workspace(min(i + max_batch, hi) - i, dev, ci)
+            for ci, (lo, hi, _) in enumerate(chunks):                # the chunks' workspaces, allocated HERE, on the caller's stream, each for the largest
+                unet.workspace(min(max_batch, hi - lo), dev, ci)     # call its slot will run (smaller calls reuse it: DiffusionUNet.workspace)
         n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
         assert 1 <= n_run <= len(seq), f"stop_at={stop_at} out of range for {len(seq)} steps"
-        for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
-            if k >= n_run:
-                x0_preds.append(None)
-                xs.append(None)
-                continue
-            at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
-            s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
-            san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
-            x0 = torch.empty_like(x)
-            xn = torch.empty_like(x)
-            if chunks is not None:
-                # independent crops: every chunk's step on its own stream (same kernels, same per-image bits)
-                _lib.set_concurrent_streams(len(chunks))              # tile rules that count one launch's workgroups count the chunks' together
-                try:
+        if chunks is not None:
+            _lib.set_concurrent_streams(len(chunks))                  # tile rules that count one launch's workgroups count the chunks' together (whole loop)
+        try:
+            for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
+                if k >= n_run:
+                    x0_preds.append(None)
+                    xs.append(None)
+                    continue
+                at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
+                s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
+                san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
+                x0 = torch.empty_like(x)
+                xn = torch.empty_like(x)
+                if chunks is not None:
+                    # independent crops: every chunk's step on its own stream (same kernels, same per-image bits)
                     for ci, (lo, hi, sc) in enumerate(chunks):
                         with torch.cuda.stream(sc):
                             stc = sc.cuda_stream
@@ -191,29 +191,31 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                                 unet.forward_nhwc(x96[i:j], t_dev[k:k + 1], eps[i:j], temb_row=None if temb is None else temb[k], ws_slot=ci)
                             _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps[lo:hi]), None, hi - lo, p, _lib.ptr(xt[lo:hi]), hi - lo, H, W, s1m, sa, san, c2,
                                                          _lib.ptr(x0[lo:hi]), _lib.ptr(xn[lo:hi]), stc))
-                finally:
-                    _lib.set_concurrent_streams(1)
+                    x0_preds.append(x0)
+                    xs.append(xn)
+                    xt = xn
+                    continue
+                if n:
+                    _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
+                for i in range(0, n, max_batch):
+                    unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
+                if sharded:
+                    _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
+                    dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
+                    _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
+                else:
+                    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
+                                                 _lib.ptr(x0), _lib.ptr(xn), st))
                 x0_preds.append(x0)
                 xs.append(xn)
                 xt = xn
-                continue
-            if n:
-                _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
-            for i in range(0, n, max_batch):
-                unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
-            if sharded:
-                _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
-                dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
-                _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
-            else:
-                _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
-                                             _lib.ptr(x0), _lib.ptr(xn), st))
-            x0_preds.append(x0)
-            xs.append(xn)
-            xt = xn
-        if chunks is not None:
-            for (_, _, sc) in chunks:
-                torch.cuda.current_stream().wait_stream(sc)            # the caller's stream sees every chunk's results
+        finally:
+            if chunks is not None:
+                # also on an exception: x96, eps, xn and the temb table are released on the caller's stream, which must not happen while a side
+                # stream's kernels may still touch them
+                _lib.set_concurrent_streams(1)
+                for (_, _, sc) in chunks:
+                    torch.cuda.current_stream().wait_stream(sc)        # the caller's stream sees every chunk's results
         if keep != "all":
             S = len(x0_preds)
             x0_preds = [t if (i - S) in keep else None for i, t in enumerate(x0_preds)]

@@ -123,7 +123,7 @@ class DiffusionUNet(nn.Module):
             self._register(key, shp)
         self._packed = None
         self._packed_sig = None
-        self._ws = {}
+        self._ws, self._ws_need, self._ws_gen = {}, {}, None
 
     @property
     def module(self):
@@ -206,14 +206,22 @@ class DiffusionUNet(nn.Module):
 
     def workspace(self, B, device, slot=0):
         """Workspace of a forward call at batch B.  slot: calls that may be in flight at the same time (one per HIP stream: sampling.ddim_sample) need one each."""
-        key = (B, str(device), slot)
-        if key not in self._ws:
-            n = int(_lib.lib().wdm_unet_workspace_bytes(self._u, B))
-            if n == 0:
+        # ONE buffer per (device, slot), sized for the largest batch the slot has run and reused for smaller ones (the library takes any buffer of at
+        # least wdm_unet_workspace_bytes(B)): chunks of different sizes on different streams never evict each other's buffers while kernels read them.
+        # Everything is dropped when the device changes or the experiment switches were re-read (they change the arena's size: _lib.env_refresh()).
+        gen = (str(device), _lib.env_generation())
+        if self._ws_gen != gen:
+            self._ws, self._ws_need, self._ws_gen = {}, {}, gen
+        need = self._ws_need.get(B)
+        if need is None:
+            need = int(_lib.lib().wdm_unet_workspace_bytes(self._u, B))
+            if need == 0:
                 raise RuntimeError("wdm_unet_workspace_bytes failed: " + _lib.lib().wdm_last_error().decode())
-            self._ws = {k: v for k, v in self._ws.items() if k[0] == B and k[1] == str(device)}      # keep only the latest size (every slot of it)
-            self._ws[key] = torch.empty(n + 256, dtype=torch.uint8, device=device)
-        return self._ws[key]
+            self._ws_need[B] = need
+        buf = self._ws.get(slot)
+        if buf is None or buf.numel() < need + 256:
+            self._ws[slot] = buf = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        return buf
 
     # ---- forward -------------------------------------------------------------------------------
     def temb_table(self, t, B=1):
