@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     using C256 = ConvDma256Cfg<4, 2, 4, 8, 16>;
     using C256h = ConvDma256Cfg<2, 4, 4, 4, 8>;
     std::vector<Variant> vars = {
-        {"t256x128", conv_dma_kernel<4, 2, 4, 4>, C128::LDS_BYTES, 16, 128, 0},
+        {"t256x128", conv_dma_kernel, C128::LDS_BYTES, 16, 128, 0},
         {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16, true>, C256::LDS_BYTES, 16, 256, 0},
         {"t256x256F", conv_dma256_kernel<4, 2, 4, 8, 16, false>, C256::LDS_BYTES, 16, 256, 0},
         {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},

@@ -7,6 +7,9 @@
 #include <stdlib.h>
 #include <vector>
 #include "conv_dma_kernel.h"
+#ifdef TILE32
+#include "conv_dma_variants.h"
+#endif
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -41,13 +44,13 @@ int main(int argc, char** argv) {
 #ifdef WDM_EPI_TS
     unsigned long long* ts; CK(hipMalloc(&ts, 128 * 8)); CK(hipMemset(ts, 0, 128 * 8)); a.ts = ts;
 #endif
-#ifdef TILE32
-    using C = ConvDmaCfgT<4, 2, 8, 4, 32, 3>;
-    auto kern = conv_dma_kernel<4, 2, 8, 4, 32, 3>;
+#ifdef TILE32              // the 512 x 128 tile of round 3 (tools/experiments/conv_dma_variants.h; add -I tools/experiments and include it)
+    using C = ConvDmaVarCfgT<4, 2, 8, 4, 32, 3>;
+    auto kern = conv_dma_var_kernel<4, 2, 8, 4, 32, 3>;
     a.mtiles = B * (H / 32) * (H / 16);
 #else
     using C = ConvDmaCfg;
-    auto kern = conv_dma_kernel<4, 2, 4, 4>;
+    auto kern = conv_dma_kernel;
     a.mtiles = B * (H / 16) * (H / 16);
 #endif
     a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;

@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     report(grid);
     {   // the non-persistent kernel on the same layer, same stamps
         const int grid1 = 8 * a.ntiles * ((a.mtiles + 7) / 8);
-        auto k1 = conv_dma_kernel<4, 2, 4, 4>;
+        auto k1 = conv_dma_kernel;
         CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, ConvDmaCfg::LDS_BYTES));
         for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k1, dim3(grid1), dim3(512), ConvDmaCfg::LDS_BYTES, 0, a);
         CK(hipEventRecord(e0, 0));

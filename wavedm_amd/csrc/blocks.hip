@@ -83,21 +83,19 @@ static int alloc_f32(Ctx& c, size_t n, float** p) {
 // keeps the 9-tap kernel everywhere (A/B runs)
 // The switches are read into a fresh EnvCfg and published through an atomic pointer: a launch path on another thread sees either the old or the new
 // set, never a half-written one (earlier configurations are kept alive: a reader may still hold a reference; a refresh is a test / A-B harness event).
-// wdm_env_refresh() must not be called with launches in flight on objects whose workspace was sized under other switches: wdm_unet_workspace_bytes is
-// re-queried by the Python layer per call; callers of the C ABI re-query after a refresh.
+// The switches change what the activation arena holds: after wdm_env_refresh() a workspace sized before it may be too small (the call then fails with
+// WDM_ENOMEM, it never overruns).  Callers of the C ABI re-query wdm_unet_workspace_bytes after a refresh; the Python layer drops its cached workspaces
+// (_lib.env_refresh() bumps a generation that DiffusionUNet.workspace() checks).
 static std::atomic<const EnvCfg*> g_env{nullptr};
 static std::mutex g_env_mu;
 void env_cfg_refresh() {
     EnvCfg* c = new EnvCfg();
     auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e ? (e[0] == '0' ? 0 : 1) : dflt; };
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    c->up4 = flag("WDM_UP4", 1); c->dma8 = flag("WDM_DMA8", 1); c->dma8_bn64 = num("WDM_DMA8_BN", 0) == 64; c->dma8_gn = num("WDM_DMA8_GN", 4);
-    c->wsm = flag("WDM_WSM", 1); c->dma32 = num("WDM_DMA32", 0); c->dma_pf = num("WDM_DMA_PF", 0) == 1; c->attn_fused = flag("WDM_ATTN_FUSED", 1);
-    c->attn_vt = flag("WDM_ATTN_VT", 1); c->fuse_nin = flag("WDM_FUSE_NIN", 1); c->gn_pass_hw = num("WDM_GN_PASS_HW", 64); c->gn_pass_cat_hw = num("WDM_GN_PASS_CAT_HW", 0); c->grid_gn = num("WDM_GRID_GN", 1);
-    c->conv_dma = num("WDM_CONV_DMA", 1) != 0; c->gemm = flag("WDM_GEMM", 1); c->bn128 = flag("WDM_CONV_BN128", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
-    c->attn_proj = flag("WDM_ATTN_PROJ", 1); c->gemm_pair = flag("WDM_GEMM_PAIR", 0); c->graph = flag("WDM_GRAPH", 0); c->gemm8 = flag("WDM_GEMM8", 0); c->gn_inline = flag("WDM_GN_INLINE", 1); c->gn_tile = num("WDM_GN_TILE", 2); c->s2_dma = num("WDM_S2_DMA", 1); c->x3_dma = flag("WDM_X3_DMA", 1); c->x3_gemm = flag("WDM_X3_GEMM", 1); c->up4_gn = num("WDM_UP4_GN", 1); c->gn_fused = flag("WDM_GN_FUSED", 1);
-    c->persist = num("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
-    c->bn256 = num("WDM_BN256", 1); c->bn256_half = flag("WDM_BN256_HALF", 0);
+    c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
+    c->persist = flag("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
+    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = flag("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2);
+    c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
 }
@@ -114,18 +112,13 @@ const EnvCfg& env_cfg() {
 }
 
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
-    return env_cfg().up4 && (dtype == WDM_BF16 || (dtype == WDM_F32X3 && env_cfg().x3_dma)) && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+    return env_cfg().up4 && (dtype == WDM_BF16 || dtype == WDM_F32X3) && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
 }
 
 int launch_conv(const ConvArgs& a0, int mode, int dtype, hipStream_t s) {
     const ConvArgs& a = a0;
     return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
 }
-int launch_gemm_pair(const ConvArgs& a0, const ConvArgs& b0, int dtype, hipStream_t s) {
-    const ConvArgs &a = a0, &b = b0;
-    return dtype == WDM_BF16 ? launch_gemm_pair_bf16(a, b, s) : dtype == WDM_F32X3 ? launch_gemm_pair_f32x3(a, b, s) : launch_gemm_pair_f32(a, b, s);
-}
-
 // ---- one fused convolution ---------------------------------------------------------------------
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
@@ -197,7 +190,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         if (want_gst) { out->gst = (float*)((char*)out->stats + sb); a.gst = out->gst; }
     }
     if (c.dry) return WDM_OK;
-    if (defer) { *defer = a; return WDM_OK; }        // the caller launches it (together with another: launch_gemm_pair)
+    if (defer) { *defer = a; return WDM_OK; }        // the caller hands it to another launcher (the fused attention core's proj_out phase)
     return launch_conv(a, mode, c.dtype, c.s);
 }
 
@@ -233,8 +226,8 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 //    conv repeats the transform: Cout / BN times);
 //  * pass: one elementwise kernel writes act(gn(x)) (and the channel concat) once, the conv runs without prologue.
 // The pass wins where the tensors are small and Cout / BN is large: the 8x8 level (768 channels: 12 N tiles).
-static bool fuse_shortcut_enabled() { return env_cfg().fuse_nin != 0; }
-static int gn_pass_max_hw() { return env_cfg().gn_pass_hw; }
+// Largest map (pixels) whose ResnetBlocks normalise in a pass: the 8 x 8 level.  (Measured: 16 x 16 neutral, 32 x 32 and up slower -- the pass is HBM-bound there.)
+static constexpr int GN_PASS_MAX_HW = 64;
 
 // partial statistics of x (its producer's, or a pass over the tensor): *tmp is what the caller has to free afterwards
 static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tmp) {
@@ -248,7 +241,7 @@ static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tm
     return WDM_OK;
 }
 
-// act(gn([x0|x1])) as one dense tensor (silu != 0: with SiLU) -- one launch (k_gn_finalize_apply), or finalize + apply per tensor with WDM_GN_FUSED=0
+// act(gn([x0|x1])) as one dense tensor (silu != 0: with SiLU) -- one launch (k_gn_finalize_apply) where that kernel takes the shape, else finalize + apply per tensor
 static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int silu, Tens* out) {
     const int C = x0.C + (x1 ? x1->C : 0);
     if (!x1 && x0.nrm && x0.nrm_for == nw.g && x0.nrm_silu == silu) {
@@ -259,7 +252,7 @@ static int materialize_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x
         src.nrm = nullptr; src.nrm_for = nullptr;
         return WDM_OK;
     }
-    if (env_cfg().gn_fused && gn_fused_pass_eligible(x0.C, x1 ? x1->C : 0, c.dtype)) {
+    if (gn_fused_pass_eligible(x0.C, x1 ? x1->C : 0, c.dtype)) {
         float *st0 = nullptr, *st1 = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
         int ns0 = 0, ns1 = 1;
         WDM_TRY(gn_partials_of(c, x0, &st0, &ns0, &tmp0));
@@ -294,14 +287,13 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
     if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
-    const bool pass = x0.H * x0.W <= gn_pass_max_hw();
+    const bool pass = x0.H * x0.W <= GN_PASS_MAX_HW;
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
     const NormW* on12 = env_cfg().gn_tile >= 2 ? &w.n2 : nullptr;      // WDM_GN_TILE=2: conv1 also normalises for conv2 on the larger maps where its kernel can
-    // channel-concat inputs on maps up to gn_pass_cat_hw pixels (the 16 x 16 up blocks: 768 ... 1280 -> 512): one pass writes act(norm1([x0 | x1])) and conv1 runs
-    // without the prologue -- its Cout / 128 = 4 N tiles each repeat the GroupNorm+SiLU of all K slabs, and these inputs need a gn_finalize launch anyway.
-    // Measured null at 16 x 16 (616.2 / 616.9 vs 617.4 / 616.8 img/s), -1.5 % with the 32 x 32 maps included: off by default (WDM_GN_PASS_CAT_HW=256 to compare)
-    const bool pass1 = pass || (x1 != nullptr && x0.H * x0.W <= env_cfg().gn_pass_cat_hw && c.dtype == WDM_BF16);
+    // (a GroupNorm+SiLU pass for the channel-concat inputs of the 16 x 16 up blocks -- whose four N tiles each repeat the transform -- measured null at 16 x 16 and
+    // -1.5 % with the 32 x 32 maps included: round 3, EXPERIMENTS.md)
+    const bool pass1 = pass;
     if (pass1) {
         Tens a1;
         WDM_TRY(materialize_gn_silu(c, w.n1, x0, x1, &a1));
@@ -322,9 +314,9 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     const bool pre2 = !pass && t1.nrm != nullptr && t1.nrm_for == w.n2.g && t1.nrm_silu == 1;
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
-    // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h unless WDM_DMA8=0)
-    const bool fuse_nin = w.has_nin && (!pass || (x0.H == 8 && x0.W == 8 && env_cfg().dma8 && c.dtype == WDM_BF16)) &&
-                          (c.dtype == WDM_BF16 || (c.dtype == WDM_F32X3 && env_cfg().x3_dma && x0.H % 16 == 0 && x0.W % 16 == 0)) && fuse_shortcut_enabled() &&
+    // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h; WDM_CONV_DMA=0 takes the LDS-DMA kernels, hence the fusion, away)
+    const bool fuse_nin = w.has_nin && env_cfg().conv_dma && (!pass || (x0.H == 8 && x0.W == 8 && c.dtype == WDM_BF16)) &&
+                          (c.dtype == WDM_BF16 || (c.dtype == WDM_F32X3 && x0.H % 16 == 0 && x0.W % 16 == 0)) &&
                           conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
     if (w.has_nin && !fuse_nin) {
@@ -363,21 +355,16 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     WDM_TRY(materialize_gn(c, w.n, x, nullptr, 0, &hn));
 
     const bool fused = attn_fused_eligible(c.dtype, N, C);
-    // q|k projection and V^T (below) read the same map and are independent: one launch for both where the GEMM kernel takes them (launch_gemm_pair)
-    const bool pair = fused && env_cfg().attn_vt != 0 && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C && env_cfg().gemm_pair;
     Tens qk;
-    ConvArgs a_qk{};
-    WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr, false, nullptr, nullptr, nullptr, nullptr,
-                     pair ? &a_qk : nullptr));                                                                      // [B][N][2C]
+    WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));      // [B][N][2C]
     void* vT = c.ar->alloc((size_t)c.B * C * N * es);                                                               // [B][C][N]
     if (!vT) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention V^T)");
     // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
-    // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  WDM_ATTN_VT=0: the conv form.
-    const bool vt_gemm = env_cfg().attn_vt != 0;
+    // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  Other shapes: the conv form with the channel-major epilogue.
     // (f32x3 mode, unfused core: the same form on conv_gemmx3_kernel.h, the bias then rides on the P.V product -- softmax rows sum to one)
-    const bool x3_vt = c.dtype == WDM_F32X3 && env_cfg().x3_dma && env_cfg().x3_gemm && N == 256;
-    const bool v_as_gemm = (fused || x3_vt) && vt_gemm && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
+    const bool x3_vt = c.dtype == WDM_F32X3 && env_cfg().conv_dma && env_cfg().gemm && N == 256;
+    const bool v_as_gemm = (fused || x3_vt) && C % 256 == 0 && w.v.rows_pad == C && w.v.cin == C;
     if (v_as_gemm) {
         if (!c.dry) {
             ConvArgs a{};
@@ -388,8 +375,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
             a.w_bytes = (unsigned)((size_t)N * hn.xs * es);
             a.alpha = 1.0f;
             a.y = vT; a.y_mode = Y_NHWC; a.y_s = N;
-            if (pair) WDM_TRY(launch_gemm_pair(a_qk, a, c.dtype, c.s));
-            else WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
+            WDM_TRY(launch_conv(a, MODE_P1, c.dtype, c.s));
         }
     } else {
         Tens dummy;
@@ -398,7 +384,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
     free_tens(c, hn);
 
     Tens o;
-    const bool fuse_proj = fused && C <= 512 && env_cfg().attn_proj && x.H == 16 && x.W == 16 && w.proj.cin == C && w.proj.cout == C;
+    const bool fuse_proj = fused && C <= 512 && env_cfg().attn_fused >= 2 && x.H == 16 && x.W == 16 && w.proj.cin == C && w.proj.cout == C;
     if (fuse_proj) {
         // ... and proj_out with its residual and the next norm's statistics as a third phase of the same kernel: O never reaches HBM
         ConvArgs a_proj{};

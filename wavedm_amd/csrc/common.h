@@ -182,40 +182,17 @@ int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hip
 // ---- experiment switches (environment), read ONCE -- at first use or when wdm_env_refresh() is called (tests and A/B harnesses that change the
 // environment inside a running process call it); no launch path calls getenv.  Defaults are the measured best.
 struct EnvCfg {
-    int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere
-    int dma8 = 1;         // WDM_DMA8=0: 8x8 convs on the register-staged kernel
-    int dma8_bn64 = 0;    // WDM_DMA8_BN=64: 64-wide N tile on every 8x8 layer
-    int dma8_gn = 4;      // WDM_DMA8_GN=1|2|4|8: N-tile groups per XCD of the 8x8 kernel
-    int wsm = 1;          // WDM_WSM=0: plain weight matrix instead of the slab-major copy
-    int dma32 = 0;        // WDM_DMA32=1|2: 512 x 128 tiles where they fill the chip / wherever the shape allows
-    int dma_pf = 0;       // WDM_DMA_PF=1: K loop that reads the next sub-stage's fragments behind its barrier
-    int attn_fused = 1;   // WDM_ATTN_FUSED=0: attention core as three launches
-    int attn_vt = 1;      // WDM_ATTN_VT=0: V^T by the conv with the channel-major epilogue
-    int fuse_nin = 1;     // WDM_FUSE_NIN=0: 1x1 shortcut as its own GEMM
-    int gn_pass_hw = 64;  // WDM_GN_PASS_HW=<pixels>: largest map that gets the GroupNorm+SiLU pass
-    int gn_pass_cat_hw = 0;   // WDM_GN_PASS_CAT_HW=<pixels>: ... for conv1 of a ResnetBlock with a channel-concat input (0: never)
-    int grid_gn = 1;      // WDM_GRID_GN=1|2|4|8: XCD tile order of the other conv kernels
-    int conv_dma = 1;     // WDM_CONV_DMA=0: no LDS-DMA 3x3 kernel
-    int gemm = 1;         // WDM_GEMM=0: 1x1 convs on the register-staged kernel
-    int bn128 = 1;        // WDM_CONV_BN128=0: 256 x 64 tiles on the register-staged 3x3 kernel
-    int bn256 = 1;        // WDM_BN256=0|1|2|3: 256-column LDS-DMA 3x3 tiles never / by workgroup count / 256-pixel tile always / 128-pixel tile always
-    int bn256_half = 0;   // WDM_BN256_HALF=1: 128 x 256 tiles where 256 x 256 ones are too few (stand-alone +4-8 %, inside the model -10 %: cold weights, one sub-stage of lead)
-    int persist = 1;      // WDM_PERSIST=0|1|2: off | persistent form of the 256 x 128 LDS-DMA 3x3 kernel (one-pass epilogue, halo prefetch | two-pass epilogue, full head prefetch)
+    int conv_dma = 1;     // WDM_CONV_DMA=0: no LDS-DMA 3x3 kernel of any mode or dtype (stride-1, 8 x 8, Downsample, sub-pixel Upsample, the f32x3 family): everything on the
+                          // register-staged conv_kernel.h -- the cross-check of the whole kernel family; fused shortcuts, in-prologue and in-tile GroupNorm go with it
+    int gemm = 1;         // WDM_GEMM=0: 1x1 convs / batched GEMMs on the register-staged kernel (bf16 and f32x3)
+    int bn256 = 1;        // WDM_BN256=0|1|2: 256-column tiles (3x3, sub-pixel upsample, 1x1 GEMM) never / where the grid still fills the chip / wherever the shape allows (same bits)
+    int persist = 1;      // WDM_PERSIST=0: no persistent form of the 256 x 128 LDS-DMA 3x3 kernel (same bits)
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
-    int gn_fused = 1;     // WDM_GN_FUSED=0: GroupNorm finalize and apply (per tensor of a concat) of the pass consumers as separate launches (same bits)
-    int attn_proj = 1;    // WDM_ATTN_PROJ=0: proj_out of the AttnBlocks as its own GEMM launch
-    int gemm_pair = 0;    // WDM_GEMM_PAIR=1: the AttnBlock's q|k and V^T GEMMs in one launch (same bits; measured +-0.1 %: 256 + 128 workgroups of 160 KB
-                          // LDS each still run one after the other on the 256 CUs, only a kernel boundary is saved)
-    int graph = 0;        // WDM_GRAPH=1: wdm_unet_forward_temb replays a captured hipGraph of the call's launches (same bits; measured no faster)
-    int gemm8 = 0;        // WDM_GEMM8=1: 1x1 convs on 8 x 8 maps (middle AttnBlock) on the LDS-DMA GEMM kernel, four images per tile -- measured 25.8 vs 22.4 us
-                          // (768->768) and 23.0 vs 23.9 (768->1536): 96 / 192 workgroups of a 12-step K loop are latency, not staging
-    int x3_gemm = 1;      // WDM_X3_GEMM=0: the f32x3 mode's 1x1 convs / batched GEMMs on the register-staged kernel
-    int x3_dma = 1;       // WDM_X3_DMA=0: the f32x3 mode's 3x3 convs on the register-staged kernel
-    int s2_dma = 1;       // WDM_S2_DMA=0: Downsample convs on the register-staged kernel; 2 / 3: 128- / 64-column tiles wherever the shape allows
     int gn_tile = 2;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h); 1: only for the consumers
                           // that normalise in a pass anyway; 2: also conv1 -> norm2 of the ResnetBlocks on 16 x 16 maps (conv2 then runs without its prologue)
     int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
-    int up4_gn = 1;       // WDM_UP4_GN=2|4|8: N-tile groups per XCD of the 8 x 8 sub-pixel upsample kernel
+    int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
+    int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
 };
 const EnvCfg& env_cfg();
@@ -223,8 +200,6 @@ void env_cfg_refresh();
 
 // ---- conv dispatch (conv_bf16.hip / conv_f32.hip) ---------------------------------------------
 int launch_conv(const ConvArgs& a, int mode, int dtype, hipStream_t s);
-// two independent 1x1 convs / batched GEMMs, in one launch where the kernels allow it (conv_gemm_kernel.h: conv_gemm_pair_kernel)
-int launch_gemm_pair(const ConvArgs& a, const ConvArgs& b, int dtype, hipStream_t s);
 
 // ---- blocks (blocks.hip) ----------------------------------------------------------------------
 // want_stats: also emit the GroupNorm partial statistics of the output (out->stats) from the conv epilogue
@@ -232,7 +207,7 @@ int launch_gemm_pair(const ConvArgs& a, const ConvArgs& b, int dtype, hipStream_
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift,
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
              bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr,
-             ConvArgs* defer = nullptr,       // defer: fill *defer instead of launching (launch_gemm_pair)
+             ConvArgs* defer = nullptr,       // defer: fill *defer instead of launching (the caller hands it to another launcher: attn.hip)
              const NormW* on = nullptr, int on_silu = 0);      // on: the consumer's norm -- out->nrm = act(GroupNorm(out)) from the conv itself where its kernel can
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 // next_n: the norm of the consumer of *out when that consumer normalises in a pass of its own (an AttnBlock, an 8 x 8 ResnetBlock): conv2 writes it (run_conv: on)

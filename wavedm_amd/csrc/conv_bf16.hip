@@ -1,5 +1,4 @@
 #define WDM_T __bf16
-#define WDM_PAIR_NAME launch_gemm_pair_bf16
 #define WDM_LAUNCH_NAME launch_conv_bf16
 #define WDM_HAS_GEMM 1
 #include "conv_gemm_kernel.h"

@@ -1,5 +1,4 @@
 #define WDM_T f32x3_t
-#define WDM_PAIR_NAME launch_gemm_pair_f32x3
 #define WDM_LAUNCH_NAME launch_conv_f32x3
 #define WDM_DTYPE_NAME "f32x3"
 #define WDM_HAS_DMAX3 1

@@ -45,7 +45,7 @@ struct GemmCfg {
     static_assert((M / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "chunks must split evenly over the waves");
 };
 
-// the workgroup's work: block `bid` of the launch described by `a` (a kernel may hold two launches: conv_gemm_pair_kernel)
+// the workgroup's work: block `bid` of the launch described by `a` (a kernel may hold two launches: tools/experiments/conv_gemm_pair_kernel.h)
 template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid, char* smem) {
     using C = GemmCfg<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
@@ -198,16 +198,6 @@ template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv_gemm_body<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>(a, blockIdx.x, smem);
-}
-
-// TWO independent GEMMs in one launch: blocks [0, nblk0) work on a0 (wave tiles of WN0 fragments), the rest on a1 -- the AttnBlock's q|k projection and
-// its V^T = W_v . h^T read the same normalised map and neither fills more than one round of workgroups, so side by side they share one launch, one
-// fill and one drain of the chip.  nblk0 is a multiple of 8 (XCD-aware tile order of either grid).
-template <int WN0, int WN1>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pair_kernel(const ConvArgs a0, const ConvArgs a1, const int nblk0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nblk0) conv_gemm_body<16, 16, 1, 4, 2, 4, WN0>(a0, blockIdx.x, smem);
-    else conv_gemm_body<16, 16, 1, 4, 2, 4, WN1>(a1, blockIdx.x - nblk0, smem);
 }
 
 }  // namespace wdm

@@ -1115,8 +1115,5 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 int launch_conv_bf16(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32x3(const ConvArgs& a, int mode, hipStream_t s);
-int launch_gemm_pair_bf16(const ConvArgs& a, const ConvArgs& b, hipStream_t s);
-int launch_gemm_pair_f32(const ConvArgs& a, const ConvArgs& b, hipStream_t s);
-int launch_gemm_pair_f32x3(const ConvArgs& a, const ConvArgs& b, hipStream_t s);
 
 }  // namespace wdm

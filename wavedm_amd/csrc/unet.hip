@@ -50,14 +50,6 @@ struct wdm_unet {
     char* packed = nullptr;
     bool all_loaded = false;
     int temb_ch = 0, temb_rows = 0;   // rows of the concatenated temb_proj matrix
-    // hipGraph replay of one forward call (wdm_unet_forward_temb): the ~240 launches of a call are captured once per (buffers, batch, switches)
-    // and replayed; see wdm_unet_forward_temb
-    struct GraphEntry { const void* x96; float* eps; void* ws; size_t wsb; int B; hipStream_t s; const void* env; const char* packed; hipGraphExec_t exec; };
-    std::vector<GraphEntry> graphs;
-    std::mutex graphs_mu;
-    hipStream_t cap_stream = nullptr;
-    std::vector<int> warmed;          // batch sizes that have run eagerly once (per-kernel function attributes are set outside any capture)
-    ~wdm_unet() { for (auto& g : graphs) hipGraphExecDestroy(g.exec); if (cap_stream) hipStreamDestroy(cap_stream); }
     size_t temb_w_off = 0, temb_b_off = 0, d0w = 0, d0b = 0, d1w = 0, d1b = 0;
     ConvD conv_in, conv_out;
     NormD norm_out;
@@ -278,7 +270,7 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
             NormW nn; int nn_silu = 0; bool have_nn = false;
             const int hw_l = (R >> l) * (R >> l);
             if (!down_attn[l].empty()) { nn = aw(down_attn[l][b]).n; have_nn = true; }
-            else if (hw_l <= env_cfg().gn_pass_hw) {
+            else if (hw_l <= 64) {           // the levels whose ResnetBlocks normalise in a pass (blocks.hip: GN_PASS_MAX_HW)
                 if (b + 1 < nrb) { nn = rw(down_res[l][b + 1], temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
                 else if (l == nres - 1) { nn = rw(mid1, temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
             }
@@ -348,9 +340,6 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// The tail of the workspace holds the temb row of a graph-replayed call (wdm_unet_forward_temb): the captured launches read it from there, whichever
-// table row the caller passes
-static constexpr size_t kTembStage = 64 * 1024;
 
 extern "C" {
 
@@ -442,7 +431,7 @@ size_t wdm_unet_workspace_bytes(const wdm_unet* u, int B) {
     // n_t = B needs B-1 more rows of temb scratch than n_t = 1: account for the larger case
     if (rc != WDM_OK) return 0;
     const size_t extra = (size_t)(B - 1) * (u->cfg.ch + 2 * (size_t)u->temb_ch + u->temb_rows) * 4 + 4096;
-    return ar.peak() + align_up(extra, 256) + 2 * kTembStage;      // + the temb row of a graph-replayed call (wdm_unet_forward_temb) and its alignment slack
+    return ar.peak() + align_up(extra, 256);
 }
 int wdm_unet_temb_rows(const wdm_unet* u) { return u ? u->temb_rows : 0; }
 int wdm_unet_temb_table(wdm_unet* u, const float* t, int n, float* temb_out, void* workspace, size_t workspace_bytes, void* stream) {
@@ -458,54 +447,11 @@ int wdm_unet_forward_temb(wdm_unet* u, const void* x96, const float* temb_row, i
     if (!u->all_loaded) WDM_FAIL(WDM_ESTATE, "wdm_unet_forward_temb: parameters not loaded");
     if (B <= 0) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward_temb: B=%d", B);
     if (((uintptr_t)workspace) & 255) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward_temb: workspace must be 256-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    auto run = [&](hipStream_t st, const float* row, size_t cap) -> int {
-        Arena ar(workspace, cap);
-        Ctx c{st, u->cfg.dtype, B, &ar, false};
-        return u->forward(c, x96, nullptr, 1, eps_out, row);
-    };
-    auto eager = [&](const float* row, size_t cap) -> int { return run(s, row, cap); };
-    // hipGraph replay (WDM_GRAPH=1; default off -- measured in round 3 on the single-stream sequence of one call: 115.8 / 116.0 img/s replayed against
-    // 116.2 / 116.1 eager at the full 100 steps: the host is never the bound (one C call per UNet forward), and the kernel-to-kernel gap on the GPU is
-    // the same for graph nodes as for eager launches).  A sampler calls this 100 times with the same buffers; the launch sequence is captured at the second call
-    // (the first runs eagerly: per-kernel attributes, first-use paths) and replayed after that -- the same kernels with the same arguments, so the same
-    // bits; what changes per call, the temb row, is copied to a fixed place at the tail of the workspace first.
-    const bool want_graph = env_cfg().graph && !prof_enabled() && (size_t)u->temb_rows * 4 <= kTembStage && workspace_bytes > 2 * kTembStage;
-    if (!want_graph) return eager(temb_row, workspace_bytes);
-    const size_t cap = (workspace_bytes - kTembStage) & ~(size_t)255;
-    float* stage = (float*)((char*)workspace + cap);
-    std::lock_guard<std::mutex> lk(u->graphs_mu);
-    bool warm = false;
-    for (int b : u->warmed) warm = warm || b == B;
-    if (!warm) { u->warmed.push_back(B); return eager(temb_row, cap); }
-    const void* envp = (const void*)&env_cfg();
-    hipGraphExec_t exec = nullptr;
-    for (auto& g : u->graphs)
-        if (g.x96 == x96 && g.eps == eps_out && g.ws == workspace && g.wsb == workspace_bytes && g.B == B && g.s == s && g.env == envp && g.packed == u->packed) exec = g.exec;
-    if (!exec) {
-        // captured on a stream of the library's own (the caller's may be the legacy default stream, which cannot capture); replayed on the caller's
-        if (!u->cap_stream && hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); u->cap_stream = nullptr; return eager(temb_row, cap); }
-        if (hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(temb_row, cap); }
-        const int rc = run(u->cap_stream, stage, cap);
-        hipGraph_t graph = nullptr;
-        const hipError_t ee = hipStreamEndCapture(u->cap_stream, &graph);
-        if (rc != WDM_OK || ee != hipSuccess || !graph) {
-            if (getenv("WDM_GRAPH_VERBOSE")) fprintf(stderr, "[wavedm] graph capture failed: rc %d, %s\n", rc, hipGetErrorString(ee));
-            if (graph) hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            if (rc != WDM_OK) return rc;
-            return eager(temb_row, cap);
-        }
-        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (ie != hipSuccess || !exec) { (void)hipGetLastError(); return eager(temb_row, cap); }
-        if (u->graphs.size() >= 8) { hipGraphExecDestroy(u->graphs.front().exec); u->graphs.erase(u->graphs.begin()); }
-        u->graphs.push_back({x96, eps_out, workspace, workspace_bytes, B, s, envp, u->packed, exec});
-        if (getenv("WDM_GRAPH_VERBOSE")) fprintf(stderr, "[wavedm] captured a UNet forward graph (B = %d, %zu cached)\n", B, u->graphs.size());
-    }
-    WDM_TRY(k_copy_f32(temb_row, stage, u->temb_rows, s));
-    WDM_HIP(hipGraphLaunch(exec, s));
-    return WDM_OK;
+    // (Round 3 could replay this call as a captured hipGraph -- WDM_GRAPH=1 --: 115.8 / 116.0 img/s against 116.2 / 116.1 eager at the full 100 steps.  The host
+    // is never the bound (one C call per UNet forward) and a graph node pays the same kernel-to-kernel gap as an eager launch; removed in round 4.)
+    Arena ar(workspace, workspace_bytes);
+    Ctx c{(hipStream_t)stream, u->cfg.dtype, B, &ar, false};
+    return u->forward(c, x96, nullptr, 1, eps_out, temb_row);
 }
 int wdm_unet_forward(wdm_unet* u, const void* x96, const float* t, int n_t, int B, float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!u || !x96 || !t || !eps_out || !workspace) WDM_FAIL(WDM_EINVAL, "wdm_unet_forward: null argument");

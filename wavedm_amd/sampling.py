@@ -152,8 +152,6 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         # chunks of independent crops, one HIP stream each (see `streams`)
         chunks = None
         ns = int(os.environ.get("WAVEDM_STREAMS", "1")) if streams is None else int(streams)
-        if os.environ.get("WDM_GRAPH", "0") not in ("", "0"):
-            ns = 1                                                    # a replayed graph has one workspace baked in
         if corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on():
             per = -(-n // ns)
             main = torch.cuda.current_stream()
