@@ -278,6 +278,9 @@ static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Te
 
 // a 3x3 conv with the GroupNorm+SiLU prologue can finalise the norm itself when it will run on an LDS-DMA 3x3 kernel (conv_dispatch.inc: bf16, 16-pixel
 // multiple maps, Cout >= 128) and its single input carries group partials (Cin = 128 / 256 / 512)
+// (maps up to 32 x 32: 16 slabs.  At 64 x 64 -- 64 slabs, 24 KB of partials per table -- the finalize costs +2.3 us per table; round 4 built it once per image in the
+// persistent kernel, which walks an image's tiles back to back and keeps the table under the packed epilogue: 609.3 / 612.9 -> 609.7 / 614.1 img/s at 20 steps, null --
+// the table set-up inside the kernel costs what the gn_finalize launch did.  Those layers keep gn_finalize.)
 static bool gn_inline_ok(const Ctx& c, const Tens& x0, const Tens* x1, int cout) {
     return env_cfg().gn_inline && env_cfg().conv_dma && c.dtype == WDM_BF16 && !x1 && x0.gst != nullptr && gn_inline_shape_ok(x0.C, x0.nslab) && x0.H % 16 == 0 &&
            x0.W % 16 == 0 && cout >= 128;
