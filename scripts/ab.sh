@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 i=0
 for v in "$@"; do
-  env $v python bench.py --steps 1 --warmup 1 --ddim-steps ${AB_DDIM:-20} --no-cpu-baseline > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.log
+  env $v python bench.py --steps 1 --warmup 1 --ddim-steps ${AB_DDIM:-20} --no-cpu-baseline ${AB_EXTRAS:---no-extras} > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.log
   echo "== $v: $(python -c "import json,sys; d=json.loads(open('gpurun_out/ab_$i.json').read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['roofline']['achieved'])")"
   i=$((i+1))
 done

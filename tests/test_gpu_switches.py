@@ -350,3 +350,35 @@ def test_f32x3_downsample_on_the_lds_dma_kernel(gu, cin, cout, B, H):
     assert any(n.startswith("convs2x3") for n in k) and any(n.startswith("conv_3x3s2") for n in k0), (k, k0)
     assert rel_linf(y, ref) <= 2e-5 and rel_linf(y0, ref) <= 2e-5
     assert torch.equal(y, run()[0])
+
+
+def test_groupnorm_finalised_by_the_producers_last_workgroups_gives_the_bits_of_gn_finalize(gu):
+    """gn_arrive.h: every conv whose consumer would otherwise need a gn_finalize launch (the 64 x 64 maps, every channel-concat input of the up path, norm_out --
+    17 per UNet call) can finalise that norm itself (WDM_GN_INLINE=2; opt-in: exact but measured slower, gn_arrive.h): its workgroups announce their tiles on a per-image counter, the last one runs gn_finalize_kernel's reduction over
+    the image's partials (read past the caches) and writes the consumer's scale / shift rows.  Same instruction sequence over the same partials in the same order,
+    whoever arrives last: the full-width UNet's output must equal WDM_GN_INLINE=1 (gn_finalize launches) BIT FOR BIT -- at several batch sizes (tile walks and
+    last arrivers differ), repeatedly (arrival order differs from run to run), and no gn_finalize launch may be left."""
+    import wavedm_amd
+    from wavedm_amd import _lib, procedural as P
+    cfg = P.raindrop_wavelet_config()
+    net = wavedm_amd.DiffusionUNet(cfg, dtype="bf16")
+    net.load_state_dict(P.procedural_state_dict(cfg), strict=True)
+    net = net.cuda()
+    t = torch.tensor([470.0])
+    for B in (3, 64, 17):
+        x = gu.seeded((B, 96, 64, 64), 100 + B).cuda()
+
+        def run():
+            _lib.prof_enable(True)
+            y = net(x, t)
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+            _lib.prof_enable(False)
+            return y, names
+        y, k = _with({"WDM_GN_INLINE": "2"}, run)
+        y1, k1 = _with({"WDM_GN_INLINE": "1"}, run)
+        n_fin, n_fin1 = sum(n == "gn_finalize_kernel" for n in k), sum(n == "gn_finalize_kernel" for n in k1)
+        print(f"B={B}: gn_finalize launches {n_fin1} -> {n_fin}")
+        assert n_fin1 == 17 and n_fin == 0, (n_fin1, n_fin)
+        assert torch.isfinite(y).all() and torch.equal(y, y1), B
+        for _ in range(3):
+            assert torch.equal(y, _with({"WDM_GN_INLINE": "2"}, lambda: net(x, t)))

@@ -41,6 +41,7 @@ int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hip
     }
     ConvArgs pe{};
     if (proj) pe = *proj;
+    pe.fin_total = AttnFusedCfg::N / AttnFusedCfg::QB;          // gn_arrive.h: the image's query blocks
     if (proj) hipLaunchKernelGGL(attn_fused_kernel<true>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
     else hipLaunchKernelGGL(attn_fused_kernel<false>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
     if (prof) prof_end(s);

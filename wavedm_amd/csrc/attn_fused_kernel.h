@@ -22,6 +22,7 @@
 // The first V^T chunks are fetched while the softmax runs.  LDS: phase 1 3 x 40 KB; phase 2 P 32 KB + 3 x 32 KB; + 1 KB of statistics.
 #pragma once
 #include "conv_kernel.h"
+#include "gn_arrive.h"
 
 namespace wdm {
 
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         __builtin_amdgcn_sched_barrier(0);
         // the workgroup's 64 queries are rows 4 qb ... 4 qb + 3 of the image's 16 x 16 map: wave row `qb` of a 256-pixel tile; its 8 waves are 8 column blocks
         conv_epilogue<T, 16, 16, 4, 4, 4>(pe, y_acc, smem, true, wave, lane, qb, wave, b, 0, 0, 0, 0, 0, EpiNoHook(), false);
+        gn_arrive<C::NTHREADS>(pe, b, 1, 256, (int*)smem, (int)threadIdx.x);       // four query blocks complete an image
     }
 }
 

@@ -61,6 +61,7 @@ void Arena::free(void* p) {
 }
 
 int alloc_tens(Ctx& c, int C, int H, int W, Tens* t) {
+    *t = Tens();                 // a reused variable must not carry the previous tensor's statistics / normalised copy / scale-shift rows (they are freed with the tensor)
     t->C = C; t->H = H; t->W = W; t->xs = C;
     t->p = c.ar->alloc((size_t)c.B * H * W * C * dsize(c.dtype));
     if (!t->p) WDM_FAIL(WDM_ENOMEM, "workspace too small (tensor %dx%dx%dx%d)", c.B, H, W, C);
@@ -70,7 +71,8 @@ void free_tens(Ctx& c, Tens& t) {
     c.ar->free(t.p);
     if (t.stats) c.ar->free(t.stats);
     if (t.nrm) c.ar->free(t.nrm);                        // a normalised copy nobody took
-    t.p = nullptr; t.stats = nullptr; t.gst = nullptr; t.nslab = 0; t.nrm = nullptr; t.nrm_for = nullptr;
+    if (t.fin_scale) { c.ar->free(t.fin_scale); c.ar->free(t.fin_shift); }      // scale / shift rows nobody took
+    t.p = nullptr; t.stats = nullptr; t.gst = nullptr; t.nslab = 0; t.nrm = nullptr; t.nrm_for = nullptr; t.fin_scale = t.fin_shift = nullptr; t.fin_for = nullptr;
 }
 
 static int alloc_f32(Ctx& c, size_t n, float** p) {
@@ -94,7 +96,7 @@ void env_cfg_refresh() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
     c->persist = flag("WDM_PERSIST", 1); c->persist_min = num("WDM_PERSIST_MIN", 100);
-    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = flag("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2);
+    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2);
     c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
@@ -123,7 +125,7 @@ int launch_conv(const ConvArgs& a0, int mode, int dtype, hipStream_t s) {
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
 int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, const float* scale, const float* shift, const float* temb,
              int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext, bool want_stats, const ConvW* shortcut,
-             const Tens* sx0, const Tens* sx1, const NormW* gn_inl, ConvArgs* defer, const NormW* on, int on_silu) {
+             const Tens* sx0, const Tens* sx1, const NormW* gn_inl, ConvArgs* defer, const NormW* on, int on_silu, const FinReq* fin) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "conv: input has %d channels, weights expect %d", Cin, w.cin);
     if (x1 && (x1->H != x0.H || x1->W != x0.W)) WDM_FAIL(WDM_EINVAL, "conv: concat inputs differ in size");
@@ -169,11 +171,12 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     }
     if (want_stats && !y_ext && w.cout % 8 == 0) {
         // the producing conv also emits the GroupNorm partial statistics of its output (no extra pass over HBM)
-        int nslab = 0, yn_ok = 0;
+        int nslab = 0, yn_ok = 0, fin_ok = 0;
         ConvArgs q = a;
-        q.query_nslab = &nslab; q.query_yn = &yn_ok;
+        q.query_nslab = &nslab; q.query_yn = &yn_ok; q.query_fin = &fin_ok;
         WDM_TRY(launch_conv(q, mode, c.dtype, c.s));
         out->nslab = nslab;
+        if (defer) fin_ok = 1;                            // (the fused attention core runs this conv as its third phase and arrives: attn_fused_kernel.h)
         if (on && yn_ok && env_cfg().gn_tile && on->c == w.cout) {
             // the kernel this conv runs on holds whole images x whole groups per tile: it also writes act(GroupNorm(out)) for the consumer (gn_group.h)
             out->nrm = c.ar->alloc((size_t)c.B * Ho * Wo * w.cout * dsize(c.dtype));
@@ -188,6 +191,19 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         if (!out->stats) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
         a.stats = out->stats; a.stats_nslab = nslab;
         if (want_gst) { out->gst = (float*)((char*)out->stats + sb); a.gst = out->gst; }
+        // the consumer's GroupNorm finalised by this launch's last workgroups (gn_arrive.h) instead of a gn_finalize launch
+        const int Cf = w.cout + ((fin && fin->other) ? fin->other->C : 0);
+        if (fin && fin_ok && env_cfg().gn_inline >= 2 && c.fin_cnt && c.fin_used < c.fin_cap && c.dtype == WDM_BF16 && fin->n->c == Cf && (!fin->other || fin->other->stats) &&
+            (double)c.B * nslab * w.cout * 16.0 < 2147483000.0) {
+            WDM_TRY(alloc_f32(c, (size_t)c.B * Cf, &out->fin_scale));
+            WDM_TRY(alloc_f32(c, (size_t)c.B * Cf, &out->fin_shift));
+            out->fin_for = fin->n->g; out->fin_other = fin->other ? fin->other->p : nullptr; out->fin_silu = fin->silu;
+            a.fin_cnt = c.fin_cnt + (size_t)c.fin_used * c.B;
+            ++c.fin_used;
+            a.fin_st1 = fin->other ? fin->other->stats : nullptr; a.fin_nslab1 = fin->other ? fin->other->nslab : 0; a.fin_C1 = fin->other ? fin->other->C : 0;
+            a.fin_gamma = fin->n->g; a.fin_beta = fin->n->b; a.fin_eps = 1e-6f; a.fin_premul = fin->silu ? -1.4426950408889634f : 1.0f;
+            a.fin_scale = out->fin_scale; a.fin_shift = out->fin_shift;          // (fin_total: the launcher, which knows the tiling)
+        }
     }
     if (c.dry) return WDM_OK;
     if (defer) { *defer = a; return WDM_OK; }        // the caller hands it to another launcher (the fused attention core's proj_out phase)
@@ -196,7 +212,21 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
 
 // GroupNorm statistics of [x0 | x1] -> scale/shift (allocated here, caller frees both).  Tensors that came out of a conv
 // carry their partial statistics already (Tens::stats); for the others a partial pass over the tensor runs first.
+static bool has_fin(const Tens& x0, const Tens* x1, const NormW& nw, int silu) {
+    return x0.fin_scale != nullptr && x0.fin_for == nw.g && x0.fin_silu == silu && x0.fin_other == (x1 ? x1->p : nullptr);
+}
+bool wants_fin(const Ctx& c, int Cin, int H, int W, bool single) {
+    if (env_cfg().gn_inline < 2 || !env_cfg().conv_dma || c.dtype != WDM_BF16 || !c.fin_cnt || H * W <= GN_PASS_MAX_HW || H % 16 || W % 16) return false;
+    const bool inl = single && env_cfg().gn_inline && gn_inline_shape_ok(Cin, (H / 16) * (W / 16) * 4);      // the consumer finalises in its own prologue (gn_inline.h)
+    return !inl;
+}
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift) {
+    if (has_fin(x0, x1, nw, for_silu_conv)) {          // the producing kernel finalised it already (gn_arrive.h); the caller owns (and frees) the rows from here
+        Tens& t = const_cast<Tens&>(x0);
+        *scale = t.fin_scale; *shift = t.fin_shift;
+        t.fin_scale = t.fin_shift = nullptr; t.fin_for = nullptr;
+        return WDM_OK;
+    }
     const int C = x0.C + (x1 ? x1->C : 0);
     const int HW = x0.H * x0.W;
     WDM_TRY(alloc_f32(c, (size_t)c.B * C, scale));
@@ -226,8 +256,6 @@ int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu
 //    conv repeats the transform: Cout / BN times);
 //  * pass: one elementwise kernel writes act(gn(x)) (and the channel concat) once, the conv runs without prologue.
 // The pass wins where the tensors are small and Cout / BN is large: the 8x8 level (768 channels: 12 N tiles).
-// Largest map (pixels) whose ResnetBlocks normalise in a pass: the 8 x 8 level.  (Measured: 16 x 16 neutral, 32 x 32 and up slower -- the pass is HBM-bound there.)
-static constexpr int GN_PASS_MAX_HW = 64;
 
 // partial statistics of x (its producer's, or a pass over the tensor): *tmp is what the caller has to free afterwards
 static int gn_partials_of(Ctx& c, const Tens& x, float** st, int* ns, float** tmp) {
@@ -286,7 +314,7 @@ static bool gn_inline_ok(const Ctx& c, const Tens& x0, const Tens* x1, int cout)
            x0.W % 16 == 0 && cout >= 128;
 }
 
-int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n, int next_silu) {
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n, int next_silu, const FinReq* next_fin) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     if (Cin != w.cin) WDM_FAIL(WDM_EINVAL, "resblock: input has %d channels, block expects %d", Cin, w.cin);
     if (!w.has_nin && x1) WDM_FAIL(WDM_EINVAL, "resblock: identity shortcut cannot take a concat input");
@@ -294,6 +322,9 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     float *sc1, *sh1, *sc2, *sh2;
     Tens t1, sct;
     const NormW* on12 = env_cfg().gn_tile >= 2 ? &w.n2 : nullptr;      // WDM_GN_TILE=2: conv1 also normalises for conv2 on the larger maps where its kernel can
+    // conv2's GroupNorm from conv1's own launch (gn_arrive.h) where neither the pass, nor conv1's in-tile GroupNorm (16 x 16 maps), nor conv2's prologue finalises it
+    const FinReq fin12{&w.n2, nullptr, 1};
+    const FinReq* f12 = (wants_fin(c, w.cout, x0.H, x0.W, true) && !(on12 && x0.H == 16 && x0.W == 16)) ? &fin12 : nullptr;
     // (a GroupNorm+SiLU pass for the channel-concat inputs of the 16 x 16 up blocks -- whose four N tiles each repeat the transform -- measured null at 16 x 16 and
     // -1.5 % with the 32 x 32 maps included: round 3, EXPERIMENTS.md)
     const bool pass1 = pass;
@@ -303,13 +334,13 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
         WDM_TRY(run_conv(c, w.c1, MODE_S1, a1, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr,
                          nullptr, pass ? &w.n2 : on12, 1));      // ... and act(norm2(h)) for conv2 where the kernel can (8 x 8 maps: conv_dma8_kernel.h; 16 x 16: on12)
         free_tens(c, a1);
-    } else if (gn_inline_ok(c, x0, x1, w.cout)) {
+    } else if (!has_fin(x0, x1, w.n1, 1) && gn_inline_ok(c, x0, x1, w.cout)) {
         // conv1's GroupNorm finalised in conv1's own prologue from the producer's group partials: no gn_finalize launch (gn_inline.h)
         WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, nullptr, nullptr, nullptr, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n1,
-                         nullptr, on12, 1));
+                         nullptr, on12, 1, f12));
     } else {
         WDM_TRY(run_gn(c, w.n1, x0, x1, 1, &sc1, &sh1));
-        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, on12, 1));
+        WDM_TRY(run_conv(c, w.c1, MODE_S1, x0, x1, sc1, sh1, w.temb, w.temb_ld, w.temb_per_image, nullptr, &t1, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, on12, 1, f12));
         c.ar->free(sc1); c.ar->free(sh1);
     }
     // conv1 wrote act(norm2(h)) itself (16 x 16 maps: its tile is the whole image): conv2 then runs WITHOUT the prologue, as on the 8 x 8 maps -- every one of
@@ -329,16 +360,16 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     if (pass || pre2) {
         Tens a2;
         WDM_TRY(materialize_gn_silu(c, w.n2, t1, nullptr, &a2));
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu, next_fin));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, a2, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu, next_fin));
         free_tens(c, a2);
-    } else if (gn_inline_ok(c, t1, nullptr, w.cout)) {
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, &w.n2, nullptr, next_n, next_silu));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n2, nullptr, next_n, next_silu));
+    } else if (!has_fin(t1, nullptr, w.n2, 1) && gn_inline_ok(c, t1, nullptr, w.cout)) {
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, &w.n2, nullptr, next_n, next_silu, next_fin));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, nullptr, nullptr, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, &w.n2, nullptr, next_n, next_silu, next_fin));
     } else {
         WDM_TRY(run_gn(c, w.n2, t1, nullptr, 1, &sc2, &sh2));
-        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu));
-        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu));
+        if (fuse_nin) WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, nullptr, out, Y_NHWC, nullptr, true, &w.nin, &x0, x1, nullptr, nullptr, next_n, next_silu, next_fin));
+        else WDM_TRY(run_conv(c, w.c2, MODE_S1, t1, nullptr, sc2, sh2, nullptr, 0, 0, res, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, next_n, next_silu, next_fin));
         c.ar->free(sc2); c.ar->free(sh2);
     }
     free_tens(c, t1);
@@ -349,7 +380,7 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
 // ---- AttnBlock: GN -> q,k,v 1x1 -> softmax(q^T k * C^-1/2) -> v.w^T -> proj_out 1x1 -> + x ----------------------
 // All four contractions run on the conv kernel: Q.K^T and P.V are 1x1 convolutions whose "weights" are the
 // image's own K (rows = keys) and V^T (rows = channels; produced by storing the v projection channel-major).
-int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
+int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* next_fin) {
     const int C = w.c, N = x.H * x.W;
     if (x.C != C) WDM_FAIL(WDM_EINVAL, "attn: input has %d channels, block expects %d", x.C, C);
     if (N % 64 || N > 512) WDM_FAIL(WDM_EINVAL, "attn: %d tokens unsupported (multiple of 64, <= 512)", N);
@@ -393,7 +424,8 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out) {
         ConvArgs a_proj{};
         Tens odummy;
         odummy.p = qk.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
-        WDM_TRY(run_conv(c, w.proj, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj));
+        WDM_TRY(run_conv(c, w.proj, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
+                         next_fin));
         if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, nullptr, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, &a_proj));
         c.ar->free(vT);
         free_tens(c, qk);

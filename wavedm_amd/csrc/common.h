@@ -68,6 +68,13 @@ struct Tens {
     void* nrm = nullptr;
     const float* nrm_for = nullptr;
     int nrm_silu = 0;
+    // the scale / shift rows of the norm whose gamma is fin_for over [this tensor | the tensor at fin_other], already finalised by the producing kernel's last
+    // workgroups (gn_arrive.h): run_gn hands them to the consumer instead of launching gn_finalize
+    float* fin_scale = nullptr;
+    float* fin_shift = nullptr;
+    const float* fin_for = nullptr;
+    const void* fin_other = nullptr;
+    int fin_silu = 0;
 };
 
 struct Ctx {
@@ -76,6 +83,10 @@ struct Ctx {
     int B;
     Arena* ar;
     bool dry;     // no launches, only arena accounting
+    // per-image arrival counters of the launches that finalise their consumer's GroupNorm (gn_arrive.h): fin_cap slots of B ints, zeroed at the start of a forward
+    // call (wdm_unet::forward); nullptr: nobody asks (the block-level entry points)
+    int* fin_cnt = nullptr;
+    int fin_cap = 0, fin_used = 0;
 };
 
 // ---- packed parameter views (device pointers) -------------------------------------------------
@@ -90,6 +101,15 @@ struct NormW {
     const float* g = nullptr;
     const float* b = nullptr;
     int c = 0;
+};
+// what consumes a conv's output next: the norm (over [output | other], other = the tensor the consumer concatenates behind it, or nullptr) whose scale / shift the
+// producer may as well finalise itself (run_conv: fin); silu: the consumer is a conv with the GroupNorm+SiLU prologue
+// Largest map (pixels) whose ResnetBlocks normalise in a pass: the 8 x 8 level.  (Measured: 16 x 16 neutral, 32 x 32 and up slower -- the pass is HBM-bound there.)
+constexpr int GN_PASS_MAX_HW = 64;
+struct FinReq {
+    const NormW* n;
+    const Tens* other;
+    int silu;
 };
 struct ResW {
     int cin = 0, cout = 0;
@@ -190,7 +210,9 @@ struct EnvCfg {
     int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_tile = 2;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h); 1: only for the consumers
                           // that normalise in a pass anyway; 2: also conv1 -> norm2 of the ResnetBlocks on 16 x 16 maps (conv2 then runs without its prologue)
-    int gn_inline = 1;    // WDM_GN_INLINE=0: gn_finalize launches instead of the in-prologue finalize of the LDS-DMA 3x3 convs
+    int gn_inline = 1;    // WDM_GN_INLINE=0: a gn_finalize launch for every conv with the GroupNorm prologue; 1 (default): finalised in the consumer's own prologue where the producer
+                          // left group partials (maps up to 32 x 32, single input: gn_inline.h); 2: everything else finalised by the PRODUCER's last workgroups (gn_arrive.h: built
+                          // in round 4, bit-identical to the launches, 3.6 % SLOWER end to end -- one workgroup per image reduces what 2 048 waves of gn_finalize do side by side)
     int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: images per batched-GEMM group of the weight gradient (training)
@@ -208,11 +230,15 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
              const float* temb, int temb_ld, int temb_per_image, const Tens* res, Tens* out, int y_mode, void* y_ext,
              bool want_stats = false, const ConvW* shortcut = nullptr, const Tens* sx0 = nullptr, const Tens* sx1 = nullptr, const NormW* gn_inl = nullptr,
              ConvArgs* defer = nullptr,       // defer: fill *defer instead of launching (the caller hands it to another launcher: attn.hip)
-             const NormW* on = nullptr, int on_silu = 0);      // on: the consumer's norm -- out->nrm = act(GroupNorm(out)) from the conv itself where its kernel can
+             const NormW* on = nullptr, int on_silu = 0,       // on: the consumer's norm -- out->nrm = act(GroupNorm(out)) from the conv itself where its kernel can
+             const FinReq* fin = nullptr);                     // fin: the consumer's norm -- its scale / shift rows from this conv's own launch where its kernel can (gn_arrive.h)
 int run_gn(Ctx& c, const NormW& nw, const Tens& x0, const Tens* x1, int for_silu_conv, float** scale, float** shift);
 // next_n: the norm of the consumer of *out when that consumer normalises in a pass of its own (an AttnBlock, an 8 x 8 ResnetBlock): conv2 writes it (run_conv: on)
-int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n = nullptr, int next_silu = 0);
-int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out);
+// next_fin: the consumer of *out when it is a conv with the GroupNorm prologue on a map too large for the pass / the in-prologue finalize (see run_conv: fin)
+int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* out, const NormW* next_n = nullptr, int next_silu = 0, const FinReq* next_fin = nullptr);
+int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* next_fin = nullptr);
+// whether the consumer (Cin channels in all, H x W map, single: no concat) takes its GroupNorm from a producer-side finalize rather than from the pass or the in-prologue finalize
+bool wants_fin(const Ctx& c, int Cin, int H, int W, bool single);
 int alloc_tens(Ctx& c, int C, int H, int W, Tens* t);
 void free_tens(Ctx& c, Tens& t);
 

@@ -19,6 +19,7 @@
 #pragma once
 #include "conv_kernel.h"
 #include "gn_inline.h"
+#include "gn_arrive.h"
 
 #ifndef WDM_DABL
 #define WDM_DABL 0
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     const int v_tile = (vy >> 4) * twn + (ox0 >> 4);
     const int v_wave_m = TH == 16 ? wave_m : ((oy0 & 8) >> 2) + wave_m;
     conv_epilogue<T, 16, TW, 4, WN, 4, EpiNoHook, false, (PACKED ? 2 : 0)>(a, acc, smem, true, wave, lane, v_wave_m, wave_n, img0, vy, ox0, n0, v_tile);      // WN / 4 passes of 64 columns
+    gn_arrive<512>(a, img0, 1, a.Hout * a.Wout, (int*)smem, (int)threadIdx.x);
 }
 
 }  // namespace wdm

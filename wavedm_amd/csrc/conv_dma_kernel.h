@@ -23,6 +23,7 @@
 #include "conv_kernel.h"
 #include "gn_inline.h"
 #include "gn_group.h"
+#include "gn_arrive.h"
 
 // tools/dma_ablate.hip builds this kernel with phases switched off (0 in the library): 1 no GroupNorm+SiLU transform, 2 no MFMAs (the
 // fragment reads stay), 4 no halo DMA after slab 0, 8 no weight DMA after the prologue, 16 no fragment reads either (with 2)
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     float4* keep_tab = a.yn != nullptr ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
     conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, 1>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, C::BN);
     if (a.yn != nullptr) gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, C::BN>(a, img0, 1, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(1, C::BN)), tid);
+    gn_arrive<C::NTHREADS>(a, img0, 1, a.Hout * a.Wout, (int*)smem, tid);       // the consumer's GroupNorm finalised by the image's last workgroup (when asked: fin_cnt)
 #ifdef WDM_WG_CLOCK
     if (threadIdx.x == 0) { a.ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); a.ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }
 #endif

@@ -16,6 +16,7 @@
 //     conservative (loads retire in order among themselves), never unsafe.
 #pragma once
 #include "conv_dma_kernel.h"
+#include "gn_arrive.h"
 
 // tools/dmap_timeline.hip: s_memtime stamps of workgroup WDM_EPI_TS, [wave][tile iteration][8]
 #ifdef WDM_EPI_TS
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
     }
     while (vb < vend && !conv_decode_tile(*ap, vb, mt, nt)) vb += vstep;
     if (vb >= vend) return;
+    int arr_cnt = 0;               // tiles of the current image finished since this workgroup last announced them (gn_arrive.h)
     int tab_img = -1;              // image whose table sits in LDS (packed epilogue only: the fp32 epilogue's tile overlays the table)
     bool tab_new = true;           // the current tile's head carried a table / partials request
     int n0, img0, tile_in_img, oy0, ox0;
@@ -352,6 +354,13 @@ __global__ __launch_bounds__(512, 2) void conv_dmap_kernel(const ConvArgs a_by_v
 #ifdef WDM_EPI_TS
         if (!more && threadIdx.x == 0) { ap->ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); ap->ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }
 #endif
+        // the consumer's GroupNorm, finalised by the image's last workgroup (when the launch asks for it): a run of tiles of one image is announced in one go
+        ++arr_cnt;
+        if (!more || img0 != c_img0) {
+            WDM_RELOAD_ARGS();
+            gn_arrive<512>(*ap, c_img0, arr_cnt, ap->Hout * ap->Wout, (int*)(smem + ConvDmaPCfg::EPI_OFF), tid);
+            arr_cnt = 0;
+        }
         if (!more) break;
         vb = vbn;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the epilogue's LDS tile (slot 0 lies under it)

@@ -41,6 +41,10 @@
 #ifndef WDM_ABL
 #define WDM_ABL 0      // ablation mask, only ever set by tools/conv_ablate.hip
 #endif
+// cache policy of the epilogues' output stores (buffer instruction aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef WDM_STORE_AUX
+#define WDM_STORE_AUX 0
+#endif
 
 namespace wdm {
 
@@ -101,6 +105,19 @@ struct ConvArgs {
     const float* on_beta;  // [Cout]
     float on_eps;
     int on_silu;
+    // producer side, GroupNorm of the CONSUMER finalised by the last workgroup of an image (gn_arrive.h): with stats and fin_cnt set, every workgroup adds its tiles
+    // to fin_cnt[image] once its statistics are out; the one that completes fin_total runs gn_finalize_kernel's reduction for the image -- over this conv's partials
+    // [| fin_st1, the partials of the tensor the consumer concatenates behind it] -- and writes the consumer's scale / shift rows.  No gn_finalize launch.
+    int* fin_cnt;          // [B], zero between launches (the last arriver resets its image's counter), or nullptr
+    int fin_total;         // tiles that complete an image: (M tiles per image) x (N tiles) of this launch
+    const float* fin_st1;  // float4[B][fin_nslab1][fin_C1] or nullptr
+    int fin_nslab1, fin_C1;
+    const float* fin_gamma; // [Cout + fin_C1]
+    const float* fin_beta;
+    float fin_eps, fin_premul;      // premul: -log2(e) for a consumer with the GroupNorm+SiLU prologue (k_gn_finalize: for_silu_conv), else 1
+    float* fin_scale;      // [B][Cout + fin_C1]
+    float* fin_shift;
+    int* query_fin;        // host only: when set, the launcher stores 1 if the kernel it would pick arrives (else 0); used with query_nslab
     int* query_yn;         // host only: when set, the launcher stores 1 if the kernel it would pick for this shape can write yn (else 0) and does not launch
     int* query_nslab;      // host only: when set, the launcher stores stats_nslab for this shape here and does not launch
     long long m_valid;     // 0: every pixel of the (B,Hout,Wout) grid exists; > 0: only the first m_valid flattened pixels do
@@ -323,6 +340,18 @@ __host__ __device__ constexpr int conv_stat_rows(int TH, int TW, int EROWS) { re
 // entry_barrier = false: the caller has already closed the main loop with a workgroup barrier (and must not have its DMA queue drained by
 // __syncthreads(), which waits vmcnt(0) while an LDS-DMA is pending).
 struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
+// one float4 of partial statistics.  When the launch finalises its consumer's GroupNorm itself (ConvArgs::fin_cnt, gn_arrive.h) another workgroup of the SAME
+// kernel reads it: written through to memory (sc0 sc1) instead of into this XCD's write-back L2
+template <class AT>
+__device__ __forceinline__ void conv_store_stat(const AT& a, long long idx, const float4& v) {
+    if (a.fin_cnt != nullptr) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)a.stats, 0, 0x7FFFFFF0, 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, (int)(idx * 16), 0, 17);
+    } else {
+        ((float4*)a.stats)[idx] = v;
+    }
+}
 // CANON: the statistics of a slab are summed in ascending order of its 16-row chunks whatever NJ is -- the association of the one-pass form
 // (NJ = WN = 4: one lane walks all rows of a column) -- so that a multi-pass epilogue writes the bits of the one-pass one.
 template <typename T, int TH, int TW, int WM, int WN, int NJ_, class WritePass, class Hook = EpiNoHook, bool CANON = false, class AT = ConvArgs>
@@ -487,13 +516,13 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 if (a.y_mode == Y_NHWC && VEC == 8) {
                     const uint4 pk = TI<T>::pack(v);
                     TI<T>::unpack(pk, vr);
-                    if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), r_y, (int)vst, 0, 0);
+                    if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), r_y, (int)vst, 0, WDM_STORE_AUX);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) vr[e] = v[e];
                     if (!(WDM_EABL & 1)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r_y, (int)vst, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7])), r_y, (int)vst + 16, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r_y, (int)vst, 0, WDM_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7])), r_y, (int)vst + 16, 0, WDM_STORE_AUX);
                     }
                 }
                 if (do_stats && row_ok) {
@@ -553,7 +582,7 @@ __device__ __forceinline__ void conv_epilogue_w(const AT& a, WritePass&& write_p
                 const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / SROWS + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
                 const int nn = ncol0 + col;
                 if ((r0 % SROWS) == 0 && nn < a.Cout && img_g < a.B)
-                    ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, (float)SROWS);
+                    conv_store_stat(a, ((long long)img_g * a.stats_nslab + slab) * a.Cout + nn, make_float4(K, s1, s2, (float)SROWS));
                 if (keep_tab != nullptr && (r0 % SROWS) == 0 && nn < a.Cout)
                     keep_tab[((m0 / (TH * TW)) * SPT + (m0 % (TH * TW)) / SROWS) * keep_bn + (nn - n0)] = make_float4(K, s1, s2, (float)SROWS);
                 if (a.gst != nullptr) {
@@ -693,7 +722,7 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
             const unsigned vst = vo_y == OOBV ? OOBV : vo_y + (unsigned)so_pix * (unsigned)a.y_s * 2u;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 pk = (it & 1) ? u32x4{tl[it].z, tl[it].w, tl[it].x, tl[it].y} : u32x4{tl[it].x, tl[it].y, tl[it].z, tl[it].w};
-            if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(pk, r_y, (int)vst, 0, 0);
+            if (!(WDM_EABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(pk, r_y, (int)vst, 0, WDM_STORE_AUX);
         }
     }
     if (call_hook) hook();
@@ -724,7 +753,7 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
         constexpr int SPT = (TH * TW) / 64;
         const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / 64 + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
         const int nn = ncol0 + col;
-        if (nn < a.Cout && img_g < a.B) ((float4*)a.stats)[((long long)img_g * a.stats_nslab + slab) * a.Cout + nn] = make_float4(K, s1, s2, 64.f);
+        if (nn < a.Cout && img_g < a.B) conv_store_stat(a, ((long long)img_g * a.stats_nslab + slab) * a.Cout + nn, make_float4(K, s1, s2, 64.f));
         if (a.gst != nullptr) {
             const int gs = a.Cout >> 5;
             const float Kg = __shfl(K, lane & ~(gs - 1));

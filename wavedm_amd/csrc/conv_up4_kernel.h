@@ -14,6 +14,7 @@
 // epilogue (conv_kernel.h) scatters the tile to the pixels of its phase and writes GroupNorm partial statistics slabs per phase.
 #pragma once
 #include "conv_kernel.h"
+#include "gn_arrive.h"
 
 namespace wdm {
 
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     conv_epilogue<T, TH, TW, WM, WN, C::EPI_NJ, EpiNoHook, false, (TH == 16 ? 1 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase);
+    // (the output map is (2 Hout) x (2 Wout); a tile of NI low-resolution images completes one tile of each)
+#pragma unroll
+    for (int k = 0; k < NI_; ++k) gn_arrive<C::NTHREADS>(a, img0 + k, 1, 4 * a.Hout * a.Wout, (int*)smem, (int)threadIdx.x);
 }
 
 }  // namespace wdm

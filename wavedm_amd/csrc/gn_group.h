@@ -3,12 +3,30 @@
 #pragma once
 #include "conv_kernel.h"
 
+#ifndef WDM_FIN_LD_AUX
+#define WDM_FIN_LD_AUX 17
+#endif
 namespace wdm {
 
 // mean / rstd of group g of image b from the partial statistics of [x0 | x1]: the work of ONE wave (all 64 lanes take part; every lane returns the result),
 // in two steps so that a wave that owns several groups can have all their loads in flight at once.  Shared by gn_finalize_kernel and
 // gn_finalize_apply_kernel so that both produce the same bits: the accumulation order per lane (ascending item index) and the shuffle tree are fixed.
 struct GnGroupLoad { float kgf; float4 v0[4]; int items, items0, n0c, cg0; };
+// FRESH0: tensor 0's partials were written by OTHER workgroups of the kernel that is reading them now (gn_arrive.h): they were stored write-through
+// (sc0 sc1) and must be loaded past the caches (sc0 sc1 as well) -- a plain load may be served by a stale L1 / L2 line (MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility").  Tensor 1 (the other half of a channel concat) always comes from an earlier kernel.
+template <bool FRESH0>
+__device__ __forceinline__ float4 gn_ld0(const float4* __restrict__ st0, long long idx) {
+    if constexpr (FRESH0) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)st0, 0, 0x7FFFFFF0, 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 16), 0, WDM_FIN_LD_AUX);          // aux 17 = sc0 | sc1
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    } else {
+        return st0[idx];
+    }
+}
+template <bool FRESH0 = false>
 __device__ __forceinline__ float4 gn_load_item(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C1, int b,
                                                const GnGroupLoad& L, int it) {
     // slab counts are powers of two for every map of the model: shifts instead of ~35-instruction run-time divisions (four per item -- they were most of
@@ -17,24 +35,25 @@ __device__ __forceinline__ float4 gn_load_item(const float4* __restrict__ st0, i
         if ((d & (d - 1)) == 0) { const int sh = __builtin_ctz(d); q = x >> sh; r = x & (d - 1); } else { q = x / d; r = x - q * d; }
     };
     int ci, sl;
-    if (it < L.items0) { divmod(it, nslab0, ci, sl); return st0[((long long)b * nslab0 + sl) * C0 + L.cg0 + ci]; }
+    if (it < L.items0) { divmod(it, nslab0, ci, sl); return gn_ld0<FRESH0>(st0, ((long long)b * nslab0 + sl) * C0 + L.cg0 + ci); }
     divmod(it - L.items0, nslab1, ci, sl);
     return st1[((long long)b * nslab1 + sl) * C1 + (L.cg0 + L.n0c + ci - C0)];
 }
+template <bool FRESH0 = false>
 __device__ __forceinline__ void gn_group_load(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int g, int b, int lane,
                                               GnGroupLoad& L) {
     const int gw = C / 32, C1 = C - C0;
     L.cg0 = g * gw;
     // ONE memory round trip: the group's pivot (first channel, slab 0) and the first batch of partials are requested before anything is used
-    const float4* kp = (L.cg0 < C0) ? &st0[((long long)b * nslab0) * C0 + L.cg0] : &st1[((long long)b * nslab1) * C1 + (L.cg0 - C0)];
-    L.kgf = kp->x;
+    L.kgf = (L.cg0 < C0) ? gn_ld0<FRESH0>(st0, ((long long)b * nslab0) * C0 + L.cg0).x : st1[((long long)b * nslab1) * C1 + (L.cg0 - C0)].x;
     // items = (channel of the group, slab of that channel's tensor); the slab counts of the two tensors may differ
     L.n0c = max(0, min(C0 - L.cg0, gw));        // channels of this group that live in tensor 0
     L.items0 = L.n0c * nslab0;
     L.items = L.items0 + (gw - L.n0c) * nslab1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) L.v0[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, lane + 64 * u);
+    for (int u = 0; u < 4; ++u) if (lane + 64 * u < L.items) L.v0[u] = gn_load_item<FRESH0>(st0, nslab0, C0, st1, nslab1, C1, b, L, lane + 64 * u);
 }
+template <bool FRESH0 = false>
 __device__ __forceinline__ void gn_group_reduce(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
                                                 int b, int lane, const GnGroupLoad& L, float& mean, float& rstd) {
     const int gw = C / 32, C1 = C - C0;
@@ -50,7 +69,7 @@ __device__ __forceinline__ void gn_group_reduce(const float4* __restrict__ st0, 
     for (int it0 = lane + 256; it0 < L.items; it0 += 256) {
         float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) v[u] = gn_load_item(st0, nslab0, C0, st1, nslab1, C1, b, L, it0 + 64 * u);
+        for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) v[u] = gn_load_item<FRESH0>(st0, nslab0, C0, st1, nslab1, C1, b, L, it0 + 64 * u);
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (it0 + 64 * u < L.items) accumulate(v[u]);
     }
@@ -66,11 +85,12 @@ __device__ __forceinline__ void gn_group_reduce(const float4* __restrict__ st0, 
     mean = (float)(kg + m);
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
+template <bool FRESH0 = false>
 __device__ __forceinline__ void gn_group_stats(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C, int HW, float eps,
                                                int g, int b, int lane, float& mean, float& rstd) {
     GnGroupLoad L;
-    gn_group_load(st0, nslab0, C0, st1, nslab1, C, g, b, lane, L);
-    gn_group_reduce(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L, mean, rstd);
+    gn_group_load<FRESH0>(st0, nslab0, C0, st1, nslab1, C, g, b, lane, L);
+    gn_group_reduce<FRESH0>(st0, nslab0, C0, st1, nslab1, C, HW, eps, b, lane, L, mean, rstd);
 }
 
 // scale / shift of one channel from its group's mean / rstd and the norm's weights (explicit fma: every caller rounds alike)
@@ -156,7 +176,7 @@ __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int
         for (int e = 0; e < VEC; e += 4) { const float4 v = *(const float4*)(src + e); f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w; }
         const int il = m / HW;
         const uint4 o = gn_apply_f8<T>(f, &tab[il * bn + col], &tab[(nimg + il) * bn + col], a.on_silu);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_n, (int)(unsigned)((((long long)img0 * HW + m) * a.Cout + n0 + col) * ES), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_n, (int)(unsigned)((((long long)img0 * HW + m) * a.Cout + n0 + col) * ES), 0, WDM_STORE_AUX);
     }
 }
 

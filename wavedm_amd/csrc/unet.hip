@@ -257,9 +257,25 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         if (!c.dry) WDM_TRY(k_pad_channels(x96, cfg.in_channels, conv_in.cin, xpad, (long long)c.B * R * R, c.dtype, c.s));
         x.p = xpad; x.C = conv_in.cin; x.xs = conv_in.cin;
     }
+    // arrival counters of the launches that finalise their consumer's GroupNorm themselves (gn_arrive.h; ~17 of them per call): one slot of B ints each, zeroed here
+    // (a last arriver resets its counter, but the arena hands out whatever the previous call left at these addresses)
+    constexpr int FIN_SLOTS = 48;
+    c.fin_cap = FIN_SLOTS; c.fin_used = 0;
+    c.fin_cnt = (int*)c.ar->alloc((size_t)FIN_SLOTS * c.B * sizeof(int));
+    if (!c.fin_cnt) WDM_FAIL(WDM_ENOMEM, "workspace too small (arrival counters)");
+    if (!c.dry) WDM_HIP(hipMemsetAsync(c.fin_cnt, 0, (size_t)FIN_SLOTS * c.B * sizeof(int), c.s));
+    // the norm a tensor meets next, for the producer to finalise (run_conv: fin) -- only where wants_fin says the consumer would otherwise launch gn_finalize
+    NormW fn;
+    FinReq fr{&fn, nullptr, 1};
+    auto fin_for = [&](const NormW& n, const Tens* other, int C0, int H, int W) -> const FinReq* {
+        if (!wants_fin(c, C0 + (other ? other->C : 0), H, W, other == nullptr)) return nullptr;
+        fn = n; fr.other = other; fr.silu = 1;
+        return &fr;
+    };
     std::vector<Tens> hs;
     Tens h;
-    WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr, true));
+    WDM_TRY(run_conv(c, cw(conv_in), MODE_S1, x, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &h, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                     fin_for(rw(down_res[0][0], temb_all, n_t).n1, nullptr, conv_in.cout, R, R)));
     if (xpad) c.ar->free(xpad);
     hs.push_back(h);
     for (int l = 0; l < nres; ++l) {
@@ -274,7 +290,10 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
                 if (b + 1 < nrb) { nn = rw(down_res[l][b + 1], temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
                 else if (l == nres - 1) { nn = rw(mid1, temb_all, n_t).n1; nn_silu = 1; have_nn = true; }
             }
-            WDM_TRY(run_resblock(c, rw(down_res[l][b], temb_all, n_t), hs.back(), nullptr, &o, have_nn ? &nn : nullptr, nn_silu));
+            // ... or the next ResnetBlock's conv1 on the larger maps: its norm1 from this block's conv2 launch (gn_arrive.h)
+            const FinReq* nf = nullptr;
+            if (down_attn[l].empty() && b + 1 < nrb) { const ResW nxt = rw(down_res[l][b + 1], temb_all, n_t); nf = fin_for(nxt.n1, nullptr, nxt.cin, R >> l, R >> l); }
+            WDM_TRY(run_resblock(c, rw(down_res[l][b], temb_all, n_t), hs.back(), nullptr, &o, have_nn ? &nn : nullptr, nn_silu, nf));
             if (!down_attn[l].empty()) {
                 Tens o2;
                 WDM_TRY(run_attn(c, aw(down_attn[l][b]), o, &o2));
@@ -305,20 +324,27 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
             Tens o;
             NormW nn;
             if (!up_attn[l].empty()) nn = aw(up_attn[l][b]).n;
-            WDM_TRY(run_resblock(c, rw(up_res[l][b], temb_all, n_t), h, &skip, &o, up_attn[l].empty() ? nullptr : &nn, 0));
+            // what meets this block's (or its AttnBlock's) output next: the next block's norm1 over [output | the next skip], or norm_out at the very end
+            const FinReq* nf = nullptr;
+            const int Rl = R >> l;
+            if (b < nrb) { const ResW nxt = rw(up_res[l][b + 1], temb_all, n_t); nf = fin_for(nxt.n1, &hs.back(), nxt.cin - hs.back().C, Rl, Rl); }
+            else if (l == 0) nf = fin_for(nw(norm_out), nullptr, cfg.ch * cfg.ch_mult[0], Rl, Rl);
+            WDM_TRY(run_resblock(c, rw(up_res[l][b], temb_all, n_t), h, &skip, &o, up_attn[l].empty() ? nullptr : &nn, 0, up_attn[l].empty() ? nf : nullptr));
             free_tens(c, h);
             free_tens(c, skip);
             h = o;
             if (!up_attn[l].empty()) {
                 Tens o2;
-                WDM_TRY(run_attn(c, aw(up_attn[l][b]), h, &o2));
+                WDM_TRY(run_attn(c, aw(up_attn[l][b]), h, &o2, nf));
                 free_tens(c, h);
                 h = o2;
             }
         }
         if (l != 0) {
             Tens o;
-            WDM_TRY(run_conv(c, cw(up_us[l]), MODE_UPS, h, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr, true));
+            const ResW nxt = rw(up_res[l - 1][0], temb_all, n_t);       // the first block of the next level: norm1 over [upsampled | skip]
+            WDM_TRY(run_conv(c, cw(up_us[l]), MODE_UPS, h, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &o, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             fin_for(nxt.n1, &hs.back(), nxt.cin - hs.back().C, 2 * (R >> l), 2 * (R >> l))));
             free_tens(c, h);
             h = o;
         }
@@ -332,6 +358,8 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
         c.ar->free(sc); c.ar->free(sh);
     }
     free_tens(c, h);
+    c.ar->free(c.fin_cnt);
+    c.fin_cnt = nullptr;
     if (!temb_pre) c.ar->free(temb_all);
     if (!hs.empty()) WDM_FAIL(WDM_ESTATE, "internal: skip stack not empty (%zu)", hs.size());
     return WDM_OK;

@@ -72,12 +72,18 @@ def psnr_from_sums(sums, H, W):
 
 
 class AsyncImageWriter:
-    def __init__(self, max_pending: int = 64):
+    """PNG output off the critical path: 8-bit conversion on the device, D2H copy on a side stream into pinned memory, encoding in worker threads.
+    `workers` threads share one queue (zlib releases the GIL): with one thread the seven PNGs per 480x720 image of restore() took 3 s of an 8-image call
+    whose sampling takes 1.5 s (bench.py: configs[4] whole pipeline); files are PIL's default encoding, as torchvision.utils.save_image writes them."""
+
+    def __init__(self, max_pending: int = 64, workers: int = 0):
         self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
-        self._thread = threading.Thread(target=self._run, name="wavedm-png-writer", daemon=True)
+        n = workers if workers > 0 else max(1, min(8, (os.cpu_count() or 2) // 2))
+        self._threads = [threading.Thread(target=self._run, name=f"wavedm-png-writer-{k}", daemon=True) for k in range(n)]
         self._stream = None
         self._errors = []
-        self._thread.start()
+        for t in self._threads:
+            t.start()
 
     def _run(self):
         from PIL import Image
@@ -122,5 +128,7 @@ class AsyncImageWriter:
 
     def close(self):
         self.flush()
-        self._q.put(None)
-        self._thread.join(timeout=10)
+        for _ in self._threads:
+            self._q.put(None)
+        for t in self._threads:
+            t.join(timeout=10)
