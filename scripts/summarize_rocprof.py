@@ -24,16 +24,17 @@ def short(name: str) -> str:
             ty = {"DF16b": "bf16", "f": "f32"}.get(m.group(1), "f32x3")
             return f"conv_{mode}_t{a[1]}x{a[2]}x{a[3]}_bn{16 * a[7] * a[5]}_{ty}"
     m = re.search(r"conv_dma_kernelI((?:Li\d+E)+)", name)
-    if m:
+    if m:                                            # rounds 1-3: a template over the wave layout
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         return f"convdma_3x3s1_t16x16x1_bn128w{a[0] * a[1]}_bf16"
+    if re.search(r"conv_dma_kernelE", name):          # round 4: the one shipped configuration
+        return "convdma_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         return f"convdma_3x3s1_t{a[4]}x16x1_bn256w8_bf16"
-    m = re.search(r"conv_dmap_kernelILb(\d)E", name)
-    if m:
-        return "convdmap_3x3s1_t16x16x1_bn128w8_bf16" + ("_2pass" if m.group(1) == "1" else "")
+    if "conv_dmap_kernel" in name:                   # <true>: packed epilogue, <false>: fp32 epilogue (residual convs) -- one name, as the library's profiler reports them
+        return "convdmap_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
     if m:
         return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn{32 * int(m.group(3) or 4)}w8_bf16"
