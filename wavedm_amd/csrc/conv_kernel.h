@@ -41,9 +41,11 @@
 #ifndef WDM_ABL
 #define WDM_ABL 0      // ablation mask, only ever set by tools/conv_ablate.hip
 #endif
-// cache policy of the epilogues' output stores (buffer instruction aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+// cache policy of the epilogues' output stores (buffer instruction aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Non-temporal: the outputs are
+// streamed once, the consumer is another kernel.  Measured (round 4, same box, 20 DDIM steps, five A/B pairs): nt +0.4 ... +1.1 % end to end in every pair,
+// write-through (sc1) +0.8 %, both together +-0; non-temporal LOADS of the halo tiles -1.5 % (the 16 tiles of an image re-read each other's borders from L2).
 #ifndef WDM_STORE_AUX
-#define WDM_STORE_AUX 0
+#define WDM_STORE_AUX 2
 #endif
 
 namespace wdm {
