@@ -27,7 +27,7 @@ def short(name: str) -> str:
     if m:                                            # rounds 1-3: a template over the wave layout
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         return f"convdma_3x3s1_t16x16x1_bn128w{a[0] * a[1]}_bf16"
-    if re.search(r"conv_dma_kernelE", name):          # round 4: the one shipped configuration
+    if re.search(r"conv_dma_kernel(E|ILb\dE)", name):          # round 4: the one shipped configuration (<true>: packed epilogue)
         return "convdma_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)", name)
     if m:

@@ -74,56 +74,3 @@ def test_resblock_bits(gu, c0, c1, cout, B, H):
     assert torch.isfinite(ys[0]).all()
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
-
-
-def _persist_modes(f):
-    from wavedm_amd import _lib
-    old = {k: os.environ.get(k) for k in ("WDM_PERSIST", "WDM_PERSIST_MIN")}
-    out = []
-    try:
-        os.environ["WDM_PERSIST_MIN"] = "1"                 # any launch of more than 2 workgroups takes the persistent form
-        for m in ("0", "1"):
-            os.environ["WDM_PERSIST"] = m
-            _lib.env_refresh()
-            out.append(f())
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        _lib.env_refresh()
-    return out
-
-
-@pytest.mark.parametrize("c0,c1,cout,B,H", [(128, 0, 128, 5, 64), (128, 128, 128, 3, 64), (256, 128, 128, 2, 64), (96, 0, 128, 7, 32), (256, 0, 128, 9, 16)])
-def test_persistent_bits(gu, c0, c1, cout, B, H):
-    """conv_dmap_kernel.h (persistent 256 x 128 tile, both epilogue forms) == conv_dma_kernel.h on whole ResnetBlocks: several tiles per workgroup
-    (the CU count of the box caps the grid; WDM_PERSIST_MIN=1 lets small launches through), statistics, temb, residual / fused shortcut."""
-    cin = c0 + c1
-    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
-              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
-    if cin != cout:
-        shapes["nin_shortcut.weight"] = (cout, cin, 1, 1)
-        shapes["nin_shortcut.bias"] = (cout,)
-    sd = gu.blk_sd("rb", shapes)
-    x0 = gu.seeded((B, c0, H, H), 5)
-    x1 = gu.seeded((B, c1, H, H), 7) if c1 else None
-    t = gu.seeded((B, 512), 6)
-    ys = _persist_modes(lambda: gu.resblock(sd, "rb", x0, x1, t, "bf16"))
-    assert torch.isfinite(ys[0]).all()
-    for y in ys[1:]:
-        assert torch.equal(ys[0], y)
-
-
-@pytest.mark.parametrize("cin,cout,B,H", [(256, 256, 2, 32), (512, 512, 3, 16), (256, 512, 1, 48)])
-def test_upsample_conv_bits(gu, cin, cout, B, H):
-    """Sub-pixel Upsample conv (conv_up4_kernel.h): 256-column tiles == 128-column ones, and both follow torch's nearest x2 + conv3x3."""
-    w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
-    b = gu.seeded((cout,), 200) * 0.1
-    x = gu.seeded((B, cin, H, H), 316)
-    ys = _modes(lambda: gu.conv(w, b, 2, x, "bf16"), modes=("0", "2", "1"))
-    for y in ys[1:]:
-        assert torch.equal(ys[0], y)
-    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
-    assert float((ys[1] - ref).abs().max() / ref.abs().max()) <= gu.TOL["bf16"]

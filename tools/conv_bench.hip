@@ -1,6 +1,6 @@
 // A/B harness for the main 3x3 conv kernels (not part of the library): runs conv_dma_kernel.h (reference) and conv_pp_kernel.h on the same
 // random inputs for a list of layer shapes, compares outputs and GroupNorm partial statistics, and times both in interleaved rounds.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I wavedm_amd/csrc -I include -I tools tools/conv_bench.hip -o tools/abl_conv_bench
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I wavedm_amd/csrc -I tools/experiments -I include -I tools tools/conv_bench.hip -o tools/abl_conv_bench
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -36,8 +36,8 @@ int main(int argc, char** argv) {
     if (argc > 4) shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 1, 0}};
     typedef void (*kern_t)(const ConvArgs);
     constexpr int NV = 5;
-    kern_t kerns_p[NV] = {conv_dma_kernel, conv_pp_kernel<0, true>, conv_pp_kernel<8, true>, conv_pp_kernel<10, true>, conv_pp_kernel<12, true>};
-    kern_t kerns_n[NV] = {conv_dma_kernel, conv_pp_kernel<0, false>, conv_pp_kernel<8, false>, conv_pp_kernel<8, false>, conv_pp_kernel<8, false>};
+    kern_t kerns_p[NV] = {conv_dma_kernel<false>, conv_pp_kernel<0, true>, conv_pp_kernel<8, true>, conv_pp_kernel<10, true>, conv_pp_kernel<12, true>};
+    kern_t kerns_n[NV] = {conv_dma_kernel<false>, conv_pp_kernel<0, false>, conv_pp_kernel<8, false>, conv_pp_kernel<8, false>, conv_pp_kernel<8, false>};
     const char* names[NV] = {"old", "pp0", "ls0", "ls2", "ls4"};
     int ldsb[NV] = {ConvDmaCfg::LDS_BYTES, ConvPPCfg::LDS_BYTES, ConvPPCfg::LDS_BYTES, ConvPPCfg::LDS_BYTES, ConvPPCfg::LDS_BYTES};
     for (int v = 0; v < NV; ++v) { CK(hipFuncSetAttribute((const void*)kerns_p[v], hipFuncAttributeMaxDynamicSharedMemorySize, ldsb[v])); CK(hipFuncSetAttribute((const void*)kerns_n[v], hipFuncAttributeMaxDynamicSharedMemorySize, ldsb[v])); }

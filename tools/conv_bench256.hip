@@ -49,7 +49,8 @@ int main(int argc, char** argv) {
     using C256 = ConvDma256Cfg<4, 2, 4, 8, 16>;
     using C256h = ConvDma256Cfg<2, 4, 4, 4, 8>;
     std::vector<Variant> vars = {
-        {"t256x128", conv_dma_kernel, C128::LDS_BYTES, 16, 128, 0},
+        {"t256x128", conv_dma_kernel<false>, C128::LDS_BYTES, 16, 128, 0},
+        {"t256x128P", conv_dma_kernel<true>, C128::LDS_BYTES, 16, 128, 0},
         {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16, true>, C256::LDS_BYTES, 16, 256, 0},
         {"t256x256F", conv_dma256_kernel<4, 2, 4, 8, 16, false>, C256::LDS_BYTES, 16, 256, 0},
         {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
@@ -129,7 +130,7 @@ int main(int argc, char** argv) {
             || !strcmp(vars[v].name, "persist1") || !strcmp(vars[v].name, "t256x256");
 #else
             || (!strcmp(vars[v].name, "persist1") && sh.res) || (!strcmp(vars[v].name, "persistF") && !sh.res)
-            || (!strcmp(vars[v].name, "t256x256") && sh.res) || (!strcmp(vars[v].name, "t256x256F") && !sh.res);
+            || (!strcmp(vars[v].name, "t256x128P") && sh.res) || (!strcmp(vars[v].name, "t256x256") && sh.res) || (!strcmp(vars[v].name, "t256x256F") && !sh.res);
 #endif
         for (int v = 0; v < NV; ++v) if (!skip[v]) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(vars[v].threads), vars[v].lds, 0, aa[v]);
         CK(hipDeviceSynchronize());

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     a.mtiles = B * (H / 32) * (H / 16);
 #else
     using C = ConvDmaCfg;
-    auto kern = conv_dma_kernel;
+    auto kern = conv_dma_kernel<false>;
     a.mtiles = B * (H / 16) * (H / 16);
 #endif
     a.ntiles = (Cout + C::BN - 1) / C::BN; a.grid_gn = 1;

@@ -1,5 +1,5 @@
 // s_memtime timeline of one persistent workgroup of conv_dmap_kernel.h (not part of the library).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWDM_EPI_TS=8 -I wavedm_amd/csrc -I include tools/dmap_timeline.hip -o tools/abl_dmap_timeline
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWDM_EPI_TS=8 -I wavedm_amd/csrc -I tools/experiments -I include tools/dmap_timeline.hip -o tools/abl_dmap_timeline
 // run:   tools/abl_dmap_timeline [B H Cin Cout pro]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     report(grid);
     {   // the non-persistent kernel on the same layer, same stamps
         const int grid1 = 8 * a.ntiles * ((a.mtiles + 7) / 8);
-        auto k1 = conv_dma_kernel;
+        auto k1 = conv_dma_kernel<false>;
         CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, ConvDmaCfg::LDS_BYTES));
         for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k1, dim3(grid1), dim3(512), ConvDmaCfg::LDS_BYTES, 0, a);
         CK(hipEventRecord(e0, 0));

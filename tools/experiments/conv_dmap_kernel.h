@@ -1,3 +1,8 @@
+// NOT IN THE LIBRARY since round 4.  Round 3 gained +1 % end to end with it (prologue of tile t + 1 under the epilogue of tile t); with the packed epilogue of round 4
+// the non-persistent kernel's tiles shrank by what this form was hiding, and the same-box A/B turned: WDM_PERSIST=1 636.6 img/s, =0 646.1 (+1.5 %, three pairs, 20
+// DDIM steps) -- four rounds of 256 plain workgroups, which the dispatcher staggers for free, beat one persistent round.  Kept with tools/conv_bench256.hip (variant
+// "persist1"), tools/dmap_timeline.hip and its measurements (EXPERIMENTS.md).
+//
 // conv_dma_kernel.h's 256 x 128 tile as a PERSISTENT workgroup: one workgroup per CU walks the tiles b, b + G, b + 2G, ... and requests the next
 // tile's scale/shift table, first halo slab and first two weight sub-stages while the current tile's epilogue is still running.
 //

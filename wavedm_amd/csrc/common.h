@@ -206,8 +206,6 @@ struct EnvCfg {
                           // register-staged conv_kernel.h -- the cross-check of the whole kernel family; fused shortcuts, in-prologue and in-tile GroupNorm go with it
     int gemm = 1;         // WDM_GEMM=0: 1x1 convs / batched GEMMs on the register-staged kernel (bf16 and f32x3)
     int bn256 = 1;        // WDM_BN256=0|1|2: 256-column tiles (3x3, sub-pixel upsample, 1x1 GEMM) never / where the grid still fills the chip / wherever the shape allows (same bits)
-    int persist = 1;      // WDM_PERSIST=0: no persistent form of the 256 x 128 LDS-DMA 3x3 kernel (same bits)
-    int persist_min = 100; // WDM_PERSIST_MIN=<percent>: persistent when the grid exceeds this share of the CU count
     int gn_tile = 2;      // WDM_GN_TILE=0: gn_finalize_apply launches instead of the in-tile GroupNorm of the producing conv's output (gn_group.h); 1: only for the consumers
                           // that normalise in a pass anyway; 2: also conv1 -> norm2 of the ResnetBlocks on 16 x 16 maps (conv2 then runs without its prologue)
     int gn_inline = 1;    // WDM_GN_INLINE=0: a gn_finalize launch for every conv with the GroupNorm prologue; 1 (default): finalised in the consumer's own prologue where the producer
