@@ -27,12 +27,13 @@ def short(name: str) -> str:
     if m:                                            # rounds 1-3: a template over the wave layout
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
         return f"convdma_3x3s1_t16x16x1_bn128w{a[0] * a[1]}_bf16"
-    if re.search(r"conv_dma_kernel(E|ILb\dE)", name):          # round 4: the one shipped configuration (<true>: packed epilogue)
-        return "convdma_3x3s1_t16x16x1_bn128w8_bf16"
-    m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)", name)
+    m = re.search(r"conv_dma_kernel(?:ILb(\d)E|<(true|false)>|E)", name)
+    if m:                                            # round 4: one configuration, <true> = bf16-tile ("packed") epilogue, <false> = fp32 epilogue
+        return f"convdma_3x3s1_t16x16x1_bn128w8{'p' if m.group(1) == '1' or m.group(2) == 'true' else ''}_bf16"
+    m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)(?:Lb(\d)E)?", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
-        return f"convdma_3x3s1_t{a[4]}x16x1_bn256w8_bf16"
+        return f"convdma_3x3s1_t{a[4]}x16x1_bn256w8{'p' if m.group(2) == '1' else ''}_bf16"
     if "conv_dmap_kernel" in name:                   # <true>: packed epilogue, <false>: fp32 epilogue (residual convs) -- one name, as the library's profiler reports them
         return "convdmap_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
