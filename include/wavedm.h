@@ -302,7 +302,15 @@ int wdm_env_refresh(void);
 /* ---- concurrent streams -------------------------------------------------------------------------
  * A caller that keeps n independent forward calls in flight on n HIP streams (wavedm_amd/sampling.py: chunks of independent crops) says so here: the tile
  * choices that follow the workgroup count of ONE launch ("256-column tiles where they still fill the chip") then count n launches side by side.  Those
- * alternatives write the same bits, so this changes speed only.  n = 1 (default): one launch owns the chip.  (No counterpart in the reference.) */
+ * alternatives write the same bits, so this changes speed only.  n = 1 (default): one launch owns the chip.  (No counterpart in the reference.)
+ *
+ * HAZARD, measured and not root-caused (EXPERIMENTS.md, round 3 "chunks of independent crops on separate HIP streams"): with four chunks on four streams the
+ * sampler gains 0 ... +5 % when every pass takes streams it has not used before, and LOSES 35 % (126 -> 83 img/s, every box) when the same four stream
+ * objects carry pass after pass -- also on every eighth pass of a caller that draws from a pool of 32.  GPU_MAX_HW_QUEUES = 1 / 2 are worse still, so the
+ * mapping of streams onto the hardware queues is involved; what exactly is not understood.  The library itself creates no streams and keeps no per-stream
+ * state (each call's scratch is the caller's workspace), so nothing here depends on which stream a call arrives on: the effect is in the runtime's queue
+ * assignment.  Until it is understood, run ONE stream per device (the default everywhere in wavedm_amd; sampling.ddim_sample(streams=) is opt-in) and do
+ * not cache side streams across passes. */
 int wdm_set_concurrent_streams(int n);
 
 #ifdef __cplusplus
