@@ -33,7 +33,7 @@ def short(name: str) -> str:
     m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)(?:Lb(\d)E)?", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
-        return f"convdma_3x3s1_t{a[4]}x16x1_bn256w8{'p' if m.group(2) == '1' else ''}_bf16"
+        return f"convdma_3x3s1_t{a[4]}x16x1_bn{16 * a[3] * a[1]}w8{'p' if m.group(2) == '1' else ''}_bf16"
     if "conv_dmap_kernel" in name:                   # <true>: packed epilogue, <false>: fp32 epilogue (residual convs) -- one name, as the library's profiler reports them
         return "convdmap_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)

@@ -1,5 +1,5 @@
-"""The 256-column tilings of the LDS-DMA 3x3 kernel (conv_dma256_kernel.h: 256 x 256 output tiles) must produce the BITS of the
-256 x 128 tile (conv_dma_kernel.h): same K order per pixel, same pixel sets and association per GroupNorm statistics slab -- the launcher picks
+"""The big tilings of the LDS-DMA 3x3 kernel (conv_dma256_kernel.h: 256 x 256 output tiles where Cout is a multiple of 256, 512 x 128 tiles -- 32 x 16 pixels --
+on maps that are multiples of 32 rows) must produce the BITS of the 256 x 128 tile (conv_dma_kernel.h): same K order per pixel, same pixel sets and association per GroupNorm statistics slab -- the launcher picks
 a tiling by workgroup count, so an image's result must not depend on it.  Checked through the C ABI on single convs (vs torch as well) and on
 whole ResnetBlocks (statistics from the epilogue, temb, residual, fused 1x1 shortcut over a concat input)."""
 import os
@@ -44,7 +44,8 @@ def _modes(f, modes=("0", "2", "1")):
     return out
 
 
-@pytest.mark.parametrize("cin,cout,B,H", [(128, 256, 2, 32), (256, 256, 3, 32), (768, 256, 1, 32), (512, 512, 3, 16), (1280, 512, 2, 16), (96, 256, 1, 48)])
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 256, 2, 32), (256, 256, 3, 32), (768, 256, 1, 32), (512, 512, 3, 16), (1280, 512, 2, 16), (96, 256, 1, 48),
+                                          (128, 128, 2, 64), (96, 128, 1, 64), (384, 128, 1, 64), (128, 128, 3, 32), (64, 384, 1, 32)])
 def test_conv_bits(gu, cin, cout, B, H):
     w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
     b = gu.seeded((cout,), 200) * 0.1
@@ -57,7 +58,7 @@ def test_conv_bits(gu, cin, cout, B, H):
 
 
 @pytest.mark.parametrize("c0,c1,cout,B,H", [(256, 0, 256, 2, 32), (256, 256, 256, 2, 32), (512, 256, 256, 1, 32), (512, 0, 512, 3, 16), (512, 512, 512, 2, 16),
-                                            (768, 512, 512, 1, 16)])
+                                            (768, 512, 512, 1, 16), (128, 0, 128, 2, 64), (128, 128, 128, 1, 64), (256, 128, 128, 1, 64), (128, 0, 128, 3, 32)])
 def test_resblock_bits(gu, c0, c1, cout, B, H):
     """conv1 (prologue over the concat, temb, statistics) and conv2 (statistics, residual or the fused 1x1 shortcut) through every tiling."""
     cin = c0 + c1

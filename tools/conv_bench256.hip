@@ -38,7 +38,7 @@ static float time_kernel(const Variant& v, int grid, const ConvArgs& a, int it) 
 
 int main(int argc, char** argv) {
     std::vector<Shape> shapes = {
-        {64, 64, 128, 128, 1, 1, 0}, {64, 64, 128, 128, 1, 0, 256}, {64, 64, 256, 128, 1, 0, 0}, {64, 64, 384, 128, 1, 0, 0}, {64, 64, 96, 128, 0, 0, 0}, {9, 64, 128, 128, 1, 1, 0}, {17, 32, 64, 128, 1, 0, 128},
+        {64, 64, 128, 128, 1, 1, 0}, {64, 64, 128, 128, 1, 0, 0}, {64, 64, 128, 128, 1, 0, 256}, {64, 64, 256, 128, 1, 0, 0}, {64, 64, 384, 128, 1, 0, 0}, {64, 64, 96, 128, 0, 0, 0}, {9, 64, 128, 128, 1, 1, 0}, {17, 32, 64, 128, 1, 0, 128},
         {64, 32, 256, 256, 1, 0, 512}, {64, 32, 256, 256, 1, 1, 0}, {64, 32, 768, 256, 1, 0, 0}, {64, 32, 512, 256, 1, 0, 0}, {64, 32, 384, 256, 1, 0, 0},
         {64, 32, 128, 256, 1, 0, 0}, {64, 16, 512, 512, 1, 0, 1024}, {64, 16, 512, 512, 1, 1, 0}, {64, 16, 1280, 512, 1, 0, 0}, {64, 16, 1024, 512, 1, 0, 0},
         {64, 16, 768, 512, 1, 0, 0}, {64, 16, 256, 512, 1, 0, 0}, {3, 16, 512, 512, 1, 1, 0}, {2, 32, 128, 256, 1, 0, 192}, {5, 48, 64, 256, 0, 0, 0},
@@ -53,6 +53,10 @@ int main(int argc, char** argv) {
         {"t256x128P", conv_dma_kernel<true>, C128::LDS_BYTES, 16, 128, 0},
         {"t256x256", conv_dma256_kernel<4, 2, 4, 8, 16, true>, C256::LDS_BYTES, 16, 256, 0},
         {"t256x256F", conv_dma256_kernel<4, 2, 4, 8, 16, false>, C256::LDS_BYTES, 16, 256, 0},
+        {"t512x128", conv_dma256_kernel<8, 1, 4, 8, 32, true, false>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
+        {"t512x128F", conv_dma256_kernel<8, 1, 4, 8, 32, false, false>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
+        {"t512x128S", conv_dma256_kernel<8, 1, 4, 8, 32, true, true>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
+        {"t512x128FS", conv_dma256_kernel<8, 1, 4, 8, 32, false, true>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
         {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
         {"persistF", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
         {"two80", conv_dma2_kernel<true>, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
@@ -125,7 +129,7 @@ int main(int argc, char** argv) {
             if (vars[i].persist && grid[i] > NCU) grid[i] = NCU;
         }
         std::vector<int> skip(NV, 0);
-        for (int v = 0; v < NV; ++v) skip[v] = (vars[v].bn == 256 && Cout % 256 != 0) || (!strncmp(vars[v].name, "two80", 5) && Cin > 768) || (!strcmp(vars[v].name, "two80") && sh.res) || (!strcmp(vars[v].name, "two80F") && !sh.res)
+        for (int v = 0; v < NV; ++v) skip[v] = (vars[v].bn == 256 && Cout % 256 != 0) || (vars[v].th == 32 && H % 32 != 0) || (!strcmp(vars[v].name, "t512x128") && (sh.res || sh.sc)) || (!strcmp(vars[v].name, "t512x128F") && (!sh.res || sh.sc)) || (!strcmp(vars[v].name, "t512x128S") && (sh.res || !sh.sc)) || (!strcmp(vars[v].name, "t512x128FS") && !sh.sc) || (!strncmp(vars[v].name, "two80", 5) && Cin > 768) || (!strcmp(vars[v].name, "two80") && sh.res) || (!strcmp(vars[v].name, "two80F") && !sh.res)
 #ifdef WDM_NO_PACK
             || !strcmp(vars[v].name, "persist1") || !strcmp(vars[v].name, "t256x256");
 #else
@@ -151,7 +155,7 @@ int main(int argc, char** argv) {
         }
         std::vector<float> t(NV, 1e9f);
         for (int round = 0; round < rounds; ++round)
-            for (int v = 0; v < NV; ++v) if (!skip[v]) t[v] = fminf(t[v], time_kernel(vars[v], grid[v], aa[v], iters));
+            for (int v = 0; v < NV; ++v) if (!skip[v] && !(v == 0 && NV > 1 && getenv("NOREF"))) t[v] = fminf(t[v], time_kernel(vars[v], grid[v], aa[v], iters));
         const double fl = 2.0 * B * H * (double)H * Cout * (9.0 * Cin + sh.sc);
         printf("B=%2d %2dx%-2d %4d->%-4d pro=%d res=%d sc=%-4d amax %.2f csum %.6g |", B, H, H, Cin, Cout, sh.pro, sh.res, sh.sc, amax, csum);
         for (int v = 0; v < NV; ++v) if (!skip[v]) printf(" %s wg %4d %6.1f us %5.0f TF (bad %zu / %zu) |", vars[v].name, grid[v], t[v], fl / t[v] / 1e6, nbad[v], nbad_s[v]);

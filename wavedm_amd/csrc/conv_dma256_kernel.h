@@ -5,10 +5,13 @@
 // DMA round trip).  With 256 columns per workgroup a layer with Cout = 256 (the 32 x 32 maps) is ONE N tile: the halo tile is fetched and
 // transformed once, and 64 images x 4 pixel tiles = 256 workgroups are exactly one round on the chip's 256 CUs instead of two.
 //
-// Two tilings, same K loop:
+// Three tilings, same K loop:
 //   <4, 2, 4, 8, 16>  256 pixels (16 x 16) x 256 channels: 8 waves of 64 x 128 (32 accumulator fragments = 128 registers of the wave's 256)
 //   <2, 4, 4, 4,  8>  128 pixels ( 8 x 16) x 256 channels: 8 waves of 64 x  64 -- for layers whose pixel tiles are too few to give every CU a
 //                     workgroup at 256 pixels (16 x 16 maps, Cout = 512: 128 workgroups -> 256)
+//   <8, 1, 4, 8, 32>  512 pixels (32 x 16) x 128 channels (round 4): the same 64 x 128 wave tile stacked eight high instead of four high and two wide -- for
+//                     layers with ONE 128-column N tile and several rounds of 256-pixel tiles (the 64 x 64 maps: 1 024 tiles -> 512): per MFMA half the
+//                     weight DMA, weight fragment reads and barriers of the 256 x 128 kernel, a 34 x 18 halo instead of two 18 x 18 ones
 // Both accumulate a pixel's K in the order of conv_dma_kernel.h (slab, dx, dy) and hand each 64-pixel wave tile to the same epilogue at the position
 // it has in the 16 x 16 tiling, so outputs AND GroupNorm partial statistics are bit-identical to the 128-column kernel: the launcher may choose by
 // workgroup count (tests/test_gpu_bn256.py).
@@ -39,19 +42,26 @@ struct ConvDma256Cfg {
     static constexpr int B_SUB = 3 * BN * 64;                               // 48 KB: one dx column
     static constexpr int B_CPW = B_SUB / 1024 / NWAVES;                     // 6
     static constexpr int B_OFF = 2 * A_BYTES;
-    static constexpr int SC_OFF = 144 * 1024;
-    static constexpr int MAX_CIN = 2048;
+    // the 512 x 128 tile: 2 x 40 KB of halo + a ring of THREE 24 KB columns (two sub-stages = 192 MFMAs per wave of lead: its weights are cold in the model)
+    // = 152 KB, table for Cin <= 1024 behind it
+    static constexpr int NRING = TH == 32 ? 3 : 2;
+    static constexpr int SC_OFF = (TH == 32 ? 152 : 144) * 1024;
+    static constexpr int MAX_CIN = TH == 32 ? 1024 : 2048;
     static constexpr int EPI_BYTES = NWAVES * 64 * 68 * 4;                  // one pass of the epilogue: 64 x 64 fp32 (+ pad) per wave
     static constexpr int G_ROWS = TH * 16;                                  // shortcut phase: pixels per stage
     static constexpr int G_STAGE = G_ROWS * 128 + BN * 128;                 // 64 KB | 48 KB
-    static constexpr int G_NBUF = TH == 16 ? 2 : 3;
+    static constexpr int G_NBUF = TH == 8 ? 3 : 2;
     static constexpr int LDS_BYTES = SC_OFF + 2 * MAX_CIN * 4;
-    static_assert(NWAVES == 8 && BN == 256 && WM == 4 && 16 * WM * WAVES_M == TH * TW && (TH == 16 || TH == 8), "(16 TH) x 256 tile on 8 waves of 64 rows");
-    static_assert(B_OFF + 2 * B_SUB <= SC_OFF && EPI_BYTES <= SC_OFF && G_NBUF * G_STAGE <= SC_OFF && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(NWAVES == 8 && WM == 4 && 16 * WM * WAVES_M == TH * TW && ((BN == 256 && (TH == 16 || TH == 8)) || (BN == 128 && TH == 32)),
+                  "(16 TH) x 256 or 512 x 128 tile on 8 waves of 64 rows");
+    // (the 512-row tile's shortcut stages, 2 x 80 KB, lie over the scale / shift table, which that phase no longer needs)
+    static_assert(B_OFF + NRING * B_SUB <= SC_OFF && EPI_BYTES <= SC_OFF && G_NBUF * G_STAGE <= (TH == 32 ? LDS_BYTES : SC_OFF) && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 // PACKED: the launcher's conv_epilogue_can_pack(a) (one epilogue form per kernel: with both, the 128 accumulator registers leave the allocator no room)
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_, bool PACKED = false>
+// SC = false: no shortcut phase in the binary (the 512 x 128 tile with the bf16-tile epilogue AND the shortcut phase leaves the allocator 60 ... 90 spilled
+// accumulator registers -- 47 MB of scratch traffic per round of workgroups, +50 us on a 64 x 64 launch; launches with a fused shortcut stay on 256 x 128)
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_, bool PACKED = false, bool SC = true>
 __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     using C = ConvDma256Cfg<WAVES_M_, WAVES_N_, WM_, WN_, TH_>;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
@@ -220,6 +230,27 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
         transform(0);
     }
     WDM_DMA_SYNC(BCP);                             // weights (0, 0) in, every lane's transform visible
+    if constexpr (C::NRING == 3) {
+        // Column (s, dx) is requested two sub-stages before it is read, right behind the barrier that frees its slot.  Queue per
+        // wave at the top of slab s (oldest first): B(s,0) landed, B(s,1); then [B(s,2)] [A(s+1)] | [B(s+1,0)] | [B(s+1,1)] join it, one group per sub-stage.
+        constexpr int sl = 0, sl1 = 1, sl2 = 2;        // three columns per slab in a ring of three: column (s, dx) always sits in slot dx
+        for (int s = 0; s < nslab; ++s) {
+            issue_b(s, 2, sl2);
+            issue_a(s + 1);                            // A[(s+1) & 1]: last read in slab s - 1
+            mfma_dx(s, 0, sl);
+            WDM_DMA_SYNC(BCP + ACP);                   // weights (s, 1) in; slot sl free
+            issue_b(s + 1, 0, sl);
+            mfma_dx(s, 1, sl1);
+            WDM_DMA_SYNC(ACP + BCP);                   // weights (s, 2) in; slot sl1 free
+            issue_b(s + 1, 1, sl1);
+            mfma_dx(s, 2, sl2);
+            if (pro && s + 1 < nslab) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BCP) : "memory");          // this lane's halo pieces of slab s + 1
+                transform(s + 1);
+            }
+            WDM_DMA_SYNC(BCP);                         // weights (s + 1, 0) and the halo slab in, transform visible; slot sl2 free
+        }
+    } else {
     // Column g = 3 s + dx sits in slot g & 1.  Queue per wave and slab:  [A(s+1)] [B(s,2)] [B(s+1,0)] [B(s+1,1)]  with B(s,1) already in flight at
     // the top; each barrier needs the column the next sub-stage reads, which is the second-youngest request at (s,0) and the youngest otherwise.
     int g = 0;
@@ -239,24 +270,31 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
         ++g;
         issue_b(s + 1, 1, (g + 1) & 1);
     }
+    }
 #undef WDM_DMA_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the clamped column requested last must not land on what follows
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (conv_dma_kernel.h / conv_gemm_kernel.h:
     // 128-byte rows, 64 channels per K step, DMA ring over the now idle operand buffers)
-    if (a.sx0 != nullptr) {
+    if (SC && a.sx0 != nullptr) {
         constexpr int G_ROWS = C::G_ROWS, G_APW = G_ROWS / 64, G_BPW = BN / 64, G_NBUF = C::G_NBUF;
         constexpr int G_STAGE = C::G_STAGE, G_A = G_ROWS * 128;
         const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
-        unsigned g_a0[G_APW], g_a1[G_APW], g_b[G_BPW];
-#pragma unroll
-        for (int i = 0; i < G_APW; ++i) {
-            const int row = (wave * G_APW + i) * 8 + (lane >> 3);
-            const int u = (lane & 7) ^ ((row >> 1) & 7);
+        // the 512-row tile has eight pixel pieces per wave and stage: their offsets are recomputed per stage (a dozen VALU beside 64 MFMAs) rather than
+        // held in sixteen registers next to the 128 accumulator registers
+        constexpr bool FLY = TH == 32;
+        unsigned g_a0[FLY ? 1 : G_APW], g_a1[FLY ? 1 : G_APW], g_b[G_BPW];
+        auto pix_off = [&](int i, int ll, unsigned& o0, unsigned& o1) __attribute__((always_inline)) {
+            const int row = (wave * G_APW + i) * 8 + (ll >> 3);
+            const int u = (ll & 7) ^ ((row >> 1) & 7);
             const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
-            g_a0[i] = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
-            g_a1[i] = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
+            o0 = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
+            o1 = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
+        };
+        if (!FLY) {
+#pragma unroll
+            for (int i = 0; i < G_APW; ++i) pix_off(i, lane, g_a0[FLY ? 0 : i], g_a1[FLY ? 0 : i]);
         }
 #pragma unroll
         for (int i = 0; i < G_BPW; ++i) {
@@ -268,12 +306,16 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
         auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
             const int c = k * 64;
             const unsigned base = lds0 + buf * G_STAGE;
-            if (c < a.sC0) {
+            int ll = lane;
+            if (FLY) asm volatile("" : "+v"(ll));              // (keeps the offsets from being hoisted out of the stage loop)
+            const bool first = c < a.sC0;
+            const i32x4 q_s = first ? q_s0 : q_s1;
+            const int cs = (first ? c : c - a.sC0) * 2;
 #pragma unroll
-                for (int i = 0; i < G_APW; ++i) dma16(q_s0, base + (wave * G_APW + i) * 1024, g_a0[i], c * 2);
-            } else {
-#pragma unroll
-                for (int i = 0; i < G_APW; ++i) dma16(q_s1, base + (wave * G_APW + i) * 1024, g_a1[i], (c - a.sC0) * 2);
+            for (int i = 0; i < G_APW; ++i) {
+                unsigned o0, o1;
+                if (FLY) pix_off(i, ll, o0, o1); else { o0 = g_a0[FLY ? 0 : i]; o1 = g_a1[FLY ? 0 : i]; }
+                dma16(q_s, base + (wave * G_APW + i) * 1024, first ? o0 : o1, cs);
             }
 #pragma unroll
             for (int i = 0; i < G_BPW; ++i) dma16(q_sw, base + G_A + (wave * G_BPW + i) * 1024, g_b[i], c * 2);
@@ -296,9 +338,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (G_NBUF == 3) { if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2); }
             else if (k + 1 < nk) issue2(k + 1, buf ^ 1);
+            if (FLY) __builtin_amdgcn_sched_barrier(0);         // (offsets, requests, then fragments: all three at once do not fit beside 128 accumulator registers)
             const char* base = smem + buf * G_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (FLY && ks) __builtin_amdgcn_sched_barrier(0);
                 uint4 af[WM];
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
@@ -320,11 +364,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue: every 64-pixel x 64-channel block of a wave goes through conv_epilogue at the place it has in the 16 x 16 / 128-column tiling
-    // (same rows per statistics slab, same slab index, same association): the 8 x 16 tile is the upper or lower half of a 16 x 16 one
+    // (same rows per statistics slab, same slab index, same association): the 8 x 16 tile is the upper or lower half of a 16 x 16 one, the 32 x 16 tile two of them
     const int twn = a.Wout / TW;
-    const int vy = oy0 & ~15;                                   // origin of the 16 x 16 tile this tile belongs to
+    const int vy = TH == 32 ? oy0 + (wave_m >> 2) * 16 : (oy0 & ~15);           // origin of the 16 x 16 tile this wave's rows belong to
     const int v_tile = (vy >> 4) * twn + (ox0 >> 4);
-    const int v_wave_m = TH == 16 ? wave_m : ((oy0 & 8) >> 2) + wave_m;
+    const int v_wave_m = TH == 16 ? wave_m : TH == 32 ? (wave_m & 3) : ((oy0 & 8) >> 2) + wave_m;
     conv_epilogue<T, 16, TW, 4, WN, 4, EpiNoHook, false, (PACKED ? 2 : 0)>(a, acc, smem, true, wave, lane, v_wave_m, wave_n, img0, vy, ox0, n0, v_tile);      // WN / 4 passes of 64 columns
     gn_arrive<512>(a, img0, 1, a.Hout * a.Wout, (int*)smem, (int)threadIdx.x);
 }
