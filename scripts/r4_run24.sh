@@ -1,0 +1,5 @@
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -3
+timeout 300 python scripts/train_bench.py --batch 64 --iters 10 2>&1 | tail -2
+WAVEDM_LIB=tools/abl_lib_prev.so timeout 300 python scripts/train_bench.py --batch 64 --iters 10 2>&1 | tail -1
+timeout 300 python scripts/train_bench.py --batch 8 --iters 10 2>&1 | tail -1

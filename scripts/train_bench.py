@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--prof", action="store_true", help="one more step under the library's per-launch event profiler: per (kernel | shape) rows on stderr")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = P.raindrop_wavelet_config()
@@ -44,6 +45,18 @@ def main():
            "ms_per_step": dt * 1e3, "samples_per_s": a.batch / dt, "loss_first": losses[0], "loss_last": float(loss),
            # forward 80 GFLOP per sample, backward ~2x
            "approx_tflops": a.batch * 79.94e9 * 3 / dt / 1e12}
+    if a.prof:
+        from wavedm_amd import _lib
+        _lib.prof_enable(True)
+        tr.train_step(x0, generator=gd)
+        torch.cuda.synchronize()
+        rows = sorted(_lib.prof_report(), key=lambda e: -e["ms"])
+        _lib.prof_enable(False)
+        tot = sum(e["ms"] for e in rows)
+        for e in rows[:60]:
+            print(f"[shape] {e['kernel']:<72s} n {e['launches']:4d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  "
+                  f"{(e['flops'] / e['ms'] / 1e9 if e['ms'] else 0):7.1f} TFLOP/s  {100 * e['ms'] / tot:5.1f}%", file=sys.stderr)
+        out["profiled_conv_ms"] = tot
     if a.cpu:
         from oracle import wavedm_oracle as O
         xs, e, t = x0[:2].cpu(), torch.randn(2, 3, 64, 64), torch.tensor([700, 120])

@@ -65,6 +65,62 @@ __global__ __launch_bounds__(256) void gather_t_kernel(const T* __restrict__ src
         TI<T>::st(dst, (b / Bg) * dst_img + ((long long)c * Bg + (b % Bg)) * kp + k, c0 < C ? tile[tx][j] : 0.f);
     }
 }
+// The same gather for bf16 tensors whose channel counts and strides are multiples of 8 (every layer of the model): 16-byte loads along the channels of a
+// pixel, 16-byte stores along the positions of a channel -- the element-wise form above moves two bytes per memory instruction and was 24 % of a training
+// step.  Same tile, same fp32 column sums in the same order.
+__global__ __launch_bounds__(256) void gather_t_bf16x8_kernel(const __bf16* __restrict__ src0, int xs0, int C0, const __bf16* __restrict__ src1, int xs1, int C, int Crows,
+                                                              int H, int W, int Ho, int Wo, int stride, int off_y, int off_x, __bf16* __restrict__ dst, long long dst_img,
+                                                              int kp, int Bg, int B, long long dst_dx, float* __restrict__ csum) {
+    __shared__ float tile[64][65];
+    __shared__ float cred[4][64];
+    const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int dxi = blockIdx.z / B;
+    const long long b = blockIdx.z - dxi * B;
+    if (gridDim.z > (unsigned)B) { off_x += dxi - 1; dst += dxi * dst_dx; }
+    const int tid = threadIdx.x;
+    if (c0 < C) {
+        const int cv = tid & 7, kl = tid >> 3;                  // 8 channel vectors x 32 positions per pass: bank (kl + 8 cv + e) % 64, conflict-free
+        const int c = c0 + cv * 8;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int j = kl + pass * 32, k = k0 + j;
+            uint4 u = make_uint4(0u, 0u, 0u, 0u);
+            if (c < C && k < Ho * Wo) {
+                const int oy = k / Wo, ox = k - oy * Wo;
+                const int y = stride * oy + off_y, x = stride * ox + off_x;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                    const long long px = (b * H + y) * W + x;
+                    u = c < C0 ? *(const uint4*)(src0 + px * xs0 + c) : *(const uint4*)(src1 + px * xs1 + (c - C0));
+                }
+            }
+            float f[8];
+            TI<__bf16>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[j][cv * 8 + e] = f[e];
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    if (csum != nullptr && c0 < C) {
+        float a4 = 0.f;
+        for (int j = ty; j < 64; j += 4) a4 += tile[j][tx];
+        cred[ty][tx] = a4;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) csum[((long long)b * gridDim.x + blockIdx.x) * C + c0 + tx] = (cred[0][tx] + cred[1][tx]) + (cred[2][tx] + cred[3][tx]);
+    }
+    const int kv = tid & 7, cl = tid >> 3;                      // 8 position vectors x 32 channel rows per pass: bank (8 kv + e + cl) % 64, conflict-free
+    const int k = k0 + kv * 8;
+    if (k >= kp) return;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int j = cl + pass * 32, c = c0 + j;
+        if (c >= Crows) break;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = c0 < C ? tile[kv * 8 + e][j] : 0.f;
+        *(uint4*)(dst + (b / Bg) * dst_img + ((long long)c * Bg + (b % Bg)) * kp + k) = TI<__bf16>::pack(f);
+    }
+}
 // grad[co][ci][tap] (OIHW f32) (+)= sum_b partial[tap][b][co][ci]   (rows_g rows per image in the partial buffer)
 __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restrict__ part, int taps, int B, int rows_g, int cout, int cin, float* __restrict__ grad,
                                                            int accumulate) {
@@ -186,8 +242,8 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__
 // ---- GroupNorm (+ SiLU) backward (unet.py:31-37 under autograd), three passes with full-row 16-byte accesses:
 //   xh = (x - mean) rstd,  pre = xh g + b,  y = silu(pre) (or pre);   dv = dy * silu'(pre)
 //   (1) sums:     per (image, pixel slab, channel)  sum dv xh  and  sum dv                       [gn_bwd_sums_kernel]
-//   (2) finalize: per (image, group) add the slabs in order -> dgamma_c, dbeta_c of the image (summed over the batch afterwards) and the
-//                 group means  ma = sum_c g_c dbeta_c / N,  mb = sum_c g_c dgamma_c / N                [gn_bwd_finalize_kernel]
+//   (2) finalize: per (image, group) add the slabs in a fixed order -> dgamma_c, dbeta_c of the image (summed over the batch afterwards) and the
+//                 group means  ma = sum_c g_c dbeta_c / N,  mb = sum_c g_c dgamma_c / N                [gn_bwd_finalize_kernel, gn_bwd_param_kernel]
 //   (3) apply:    dx = rstd (dv g - ma - xh mb)                                                    [gn_bwd_apply_kernel]
 // x = [x0 | x1] (channel concat), dy dense [B][HW][C]; dx0 / dx1 dense per source, optionally accumulated into.
 template <typename T>
@@ -265,34 +321,48 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ 
         for (int e = 0; e < VEC; ++e) dst[e] = make_float2(sg[e], sb[e]);
     }
 }
-// grid (32 groups), 256 threads: every (image, channel of the group) pair adds its slabs in ascending order; then per image the group means
-// (mab) and per channel the batch sums dgamma / dbeta (images in ascending order), all inside the workgroup
+// Finalize in two launches (round 4: ONE workgroup per group walking B x gw channels x nslab slabs serially was 48 us on 32 of 256 CUs, 5 % of a step):
+//   (2a) grid (32 groups, B images), 256 threads: a channel's slabs are summed by eight lanes (slab sl goes to lane sl % 8, ascending within a lane; the eight
+//        partial sums are joined by a fixed xor tree) -> dgamma_c, dbeta_c of the image; then the image's group means (mab), channels in ascending order;
+//   (2b) one thread per channel and parameter: the batch sum over the images in ascending order.
+// Every order is fixed: deterministic.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __restrict__ partial, int nslab, int B, int C, int HW, const float* __restrict__ gamma,
-                                                             float* __restrict__ dgam_part, float* __restrict__ dbet_part, float* __restrict__ mab,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int gw = C / 32, cg0 = g * gw;
-    for (int i = tid; i < B * gw; i += 256) {
-        const int b = i / gw, c = cg0 + (i - b * gw);
+                                                             float* __restrict__ dgam_part, float* __restrict__ dbet_part, float* __restrict__ mab) {
+    __shared__ float sgs[64], sbs[64];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int gw = C / 32, cg0 = g * gw;                        // gw <= 64 (C <= 2048)
+    for (int i = tid; i < ((gw * 8 + 63) & ~63); i += 256) {    // whole waves take part in the shuffles
+        const int ci = i >> 3, part = i & 7;
         float sg = 0.f, sb = 0.f;
-        for (int sl = 0; sl < nslab; ++sl) { const float2 v = partial[((long long)b * nslab + sl) * C + c]; sg += v.x; sb += v.y; }
-        dgam_part[(long long)b * C + c] = sg; dbet_part[(long long)b * C + c] = sb;
+        if (ci < gw) {
+            const int c = cg0 + ci;
+            for (int sl = part; sl < nslab; sl += 8) { const float2 v = partial[((long long)b * nslab + sl) * C + c]; sg += v.x; sb += v.y; }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
+        if (part == 0 && ci < gw) {
+            dgam_part[(long long)b * C + cg0 + ci] = sg; dbet_part[(long long)b * C + cg0 + ci] = sb;
+            sgs[ci] = sg; sbs[ci] = sb;
+        }
     }
-    __syncthreads();                                   // the per-image sums were written by this workgroup
-    const float N = (float)gw * (float)HW;
-    for (int b = tid; b < B; b += 256) {
+    __syncthreads();
+    if (tid == 0) {
+        const float N = (float)gw * (float)HW;
         float Sa = 0.f, Sb = 0.f;
-        for (int ci = 0; ci < gw; ++ci) { const int c = cg0 + ci; Sa += gamma[c] * dbet_part[(long long)b * C + c]; Sb += gamma[c] * dgam_part[(long long)b * C + c]; }
+        for (int ci = 0; ci < gw; ++ci) { Sa += gamma[cg0 + ci] * sbs[ci]; Sb += gamma[cg0 + ci] * sgs[ci]; }
         mab[((long long)b * 32 + g) * 2] = Sa / N; mab[((long long)b * 32 + g) * 2 + 1] = Sb / N;
     }
-    for (int i = tid; i < 2 * gw; i += 256) {
-        const int c = cg0 + (i < gw ? i : i - gw);
-        const float* src = i < gw ? dgam_part : dbet_part;
-        float* out = i < gw ? dgamma : dbeta;
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += src[(long long)b * C + c];
-        out[c] = accumulate ? out[c] + t : t;
-    }
+}
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ dgam_part, const float* __restrict__ dbet_part, int B, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    const int c = i < C ? i : i - C;
+    const float* src = i < C ? dgam_part : dbet_part;
+    float* out = i < C ? dgamma : dbeta;
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += src[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + t : t;
 }
 // elementwise over (image, pixel, 16-byte channel vector)
 template <typename T>
@@ -346,7 +416,8 @@ static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, 
     const int cols = C / VEC;
     hipLaunchKernelGGL(gn_bwd_sums_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nslab, (const T*)dy, g,
                        bta, mr, silu, partial);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32), dim3(256), 0, s, partial, nslab, B, C, HW, g, dgp, dbp, mab, dgamma, dbeta, acc_param);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, B), dim3(256), 0, s, partial, nslab, B, C, HW, g, dgp, dbp, mab);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, dgp, dbp, B, C, dgamma, dbeta, acc_param);
     const long long nvec = (long long)B * HW * cols;
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(nblk(nvec, 256)), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nvec, (const T*)dy, g, bta, mr, mab,
                        silu, (T*)dx0, acc0, (T*)dx1, acc1);
@@ -361,6 +432,14 @@ static void gather_t(hipStream_t s, const void* src0, int xs0, int C0, const voi
     // dst group stride is rows_per_img * Bg * kp; rows C .. zero_rows_to-1 of every image are zero-filled (the GEMM's padded M rows)
     const int C = C0 + C1;
     const int crows = zero_rows_to > C ? zero_rows_to : C;
+    if constexpr (sizeof(T) == 2) {
+        if (C0 % 8 == 0 && C1 % 8 == 0 && xs0 % 8 == 0 && (src1 == nullptr || xs1 % 8 == 0) && kp % 8 == 0 && dst_dx % 8 == 0 && ((size_t)dst & 15) == 0) {
+            hipLaunchKernelGGL(gather_t_bf16x8_kernel, dim3((kp + 63) / 64, (crows + 63) / 64, B * ndx), dim3(256), 0, s, (const __bf16*)src0, xs0, C0,
+                               (const __bf16*)(src1 ? src1 : src0), xs1, C, crows, H, W, Ho, Wo, stride, off_y, off_x, (__bf16*)dst, (long long)rows_per_img * Bg * kp, kp, Bg, B,
+                               dst_dx, csum);
+            return;
+        }
+    }
     hipLaunchKernelGGL(gather_t_kernel<T>, dim3((kp + 63) / 64, (crows + 63) / 64, B * ndx), dim3(256), 0, s, (const T*)src0, xs0, C0, (const T*)(src1 ? src1 : src0), xs1, C,
                        crows, H, W, Ho, Wo, stride, off_y, off_x, (T*)dst, (long long)rows_per_img * Bg * kp, kp, Bg, B, dst_dx, csum);
 }
