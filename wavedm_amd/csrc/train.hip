@@ -246,21 +246,6 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__
 //                 group means  ma = sum_c g_c dbeta_c / N,  mb = sum_c g_c dgamma_c / N                [gn_bwd_finalize_kernel, gn_bwd_param_kernel]
 //   (3) apply:    dx = rstd (dv g - ma - xh mb)                                                    [gn_bwd_apply_kernel]
 // x = [x0 | x1] (channel concat), dy dense [B][HW][C]; dx0 / dx1 dense per source, optionally accumulated into.
-template <typename T>
-__device__ __forceinline__ void gn_bwd_load(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, const T* __restrict__ dy, long long bp,
-                                            int c, const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd, int silu, float* xh,
-                                            float* dv) {
-    constexpr int VEC = TI<T>::VEC;
-    const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
-    const uint4 ud = *(const uint4*)(dy + bp * C + c);
-    TI<T>::unpack(ux, xh);
-    TI<T>::unpack(ud, dv);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        xh[e] = (xh[e] - mean) * rstd;
-        if (silu) { const float pre = xh[e] * gamma[c + e] + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv[e] *= sgm * (1.0f + pre * (1.0f - sgm)); }
-    }
-}
 // grid (nslab, B, column blocks): 256 threads = (pixel rows) x (16-byte channel vectors); partial[b][slab][c] = {sum dv xh, sum dv}
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW, int nslab,
@@ -283,25 +268,28 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
     if (row < rows) {
-        const int g = c / gw;                                    // VEC divides gw (C % 256 == 0 for bf16, % 128 for f32) or the vector straddles: per element below
+        // the vector's statistics, gamma and beta are loop constants: in registers, per element (a vector may straddle a group boundary when gw % VEC != 0)
+        float gm[VEC], bt[VEC], mean[VEC], rstd[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int ge = (c + e) / gw;
+            gm[e] = gamma[c + e]; bt[e] = beta[c + e];
+            mean[e] = mean_rstd[((long long)b * 32 + ge) * 2]; rstd[e] = mean_rstd[((long long)b * 32 + ge) * 2 + 1];
+        }
+        const bool first = c < C0;
+        const T* xp = first ? x0 + c : x1 + (c - C0);
+        const int xs = first ? xs0 : xs1;
         for (int p = p0 + row; p < p1; p += rows) {
             float xh[VEC], dv[VEC];
-            if ((c + VEC - 1) / gw == g) {
-                const float mean = mean_rstd[((long long)b * 32 + g) * 2], rstd = mean_rstd[((long long)b * 32 + g) * 2 + 1];
-                gn_bwd_load<T>(x0, xs0, C0, x1, xs1, C, dy, (long long)b * HW + p, c, gamma, beta, mean, rstd, silu, xh, dv);
-            } else {                                             // group boundary inside the vector (gw not a multiple of VEC): element-wise statistics
-                const long long bp = (long long)b * HW + p;
-                const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
-                const uint4 ud = *(const uint4*)(dy + bp * C + c);
-                TI<T>::unpack(ux, xh);
-                TI<T>::unpack(ud, dv);
+            const long long bp = (long long)b * HW + p;
+            const uint4 ux = *(const uint4*)(xp + bp * xs);
+            const uint4 ud = *(const uint4*)(dy + bp * C + c);
+            TI<T>::unpack(ux, xh);
+            TI<T>::unpack(ud, dv);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const int ge = (c + e) / gw;
-                    const float mean = mean_rstd[((long long)b * 32 + ge) * 2], rstd = mean_rstd[((long long)b * 32 + ge) * 2 + 1];
-                    xh[e] = (xh[e] - mean) * rstd;
-                    if (silu) { const float pre = xh[e] * gamma[c + e] + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv[e] *= sgm * (1.0f + pre * (1.0f - sgm)); }
-                }
+            for (int e = 0; e < VEC; ++e) {
+                xh[e] = (xh[e] - mean[e]) * rstd[e];
+                if (silu) { const float pre = xh[e] * gm[e] + bt[e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); dv[e] *= sgm * (1.0f + pre * (1.0f - sgm)); }
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { sg[e] += dv[e] * xh[e]; sb[e] += dv[e]; }
@@ -364,36 +352,54 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
     for (int b = 0; b < B; ++b) t += src[(long long)b * C + c];
     out[c] = accumulate ? out[c] + t : t;
 }
-// elementwise over (image, pixel, 16-byte channel vector)
+// elementwise over (image, pixel, 16-byte channel vector).  grid (pixel chunks, B, column blocks): a thread keeps ONE channel vector -- its group statistics,
+// gamma and beta live in registers, and no index in the pixel loop divides by a run-time value (the first form did eleven such divisions per vector and ran
+// at a fifth of the memory rate).  Same arithmetic per element.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW, long long nvec,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x0, int xs0, int C0, const T* __restrict__ x1, int xs1, int C, int HW,
                                                            const T* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ mab, int silu, T* __restrict__ dx0, int acc0,
                                                            T* __restrict__ dx1, int acc1) {
     constexpr int VEC = TI<T>::VEC;
     const int cols = C / VEC, gw = C / 32, C1 = C - C0;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec; id += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(id % cols) * VEC;
-        const long long bp = id / cols;
-        const long long b = bp / HW;
-        const uint4 ux = c < C0 ? *(const uint4*)(x0 + bp * xs0 + c) : *(const uint4*)(x1 + bp * xs1 + (c - C0));
+    const int cb = blockIdx.z;
+    const int cols_here = min(cols - cb * 256, 256);
+    const int rows = 256 / cols_here;
+    const int tid = threadIdx.x;
+    const int col = tid % cols_here, row = tid / cols_here;
+    if (row >= rows) return;
+    const int c = (cb * 256 + col) * VEC;
+    const long long b = blockIdx.y;
+    float gm[VEC], bt[VEC], mean[VEC], rstd[VEC], ma[VEC], mb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (c + e) / gw;
+        gm[e] = gamma[c + e]; bt[e] = beta[c + e];
+        mean[e] = mean_rstd[(b * 32 + g) * 2]; rstd[e] = mean_rstd[(b * 32 + g) * 2 + 1];
+        ma[e] = mab[(b * 32 + g) * 2]; mb[e] = mab[(b * 32 + g) * 2 + 1];
+    }
+    const bool first = c < C0;
+    const T* xp = first ? x0 + c : x1 + (c - C0);
+    const int xs = first ? xs0 : xs1;
+    T* dp = first ? dx0 + c : dx1 + (c - C0);
+    const int ds = first ? C0 : C1;
+    const int acc = first ? acc0 : acc1;
+    for (int p = blockIdx.x * rows + row; p < HW; p += gridDim.x * rows) {
+        const long long bp = b * HW + p;
+        const uint4 ux = *(const uint4*)(xp + bp * xs);
         const uint4 ud = *(const uint4*)(dy + bp * C + c);
         float xh[VEC], dv[VEC], d[VEC];
         TI<T>::unpack(ux, xh);
         TI<T>::unpack(ud, dv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const int g = (c + e) / gw;
-            const float mean = mean_rstd[(b * 32 + g) * 2], rstd = mean_rstd[(b * 32 + g) * 2 + 1];
-            const float ma = mab[(b * 32 + g) * 2], mb = mab[(b * 32 + g) * 2 + 1];
-            const float gm = gamma[c + e];
-            const float h = (xh[e] - mean) * rstd;
+            const float h = (xh[e] - mean[e]) * rstd[e];
             float v = dv[e];
-            if (silu) { const float pre = h * gm + beta[c + e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); v *= sgm * (1.0f + pre * (1.0f - sgm)); }
-            d[e] = rstd * (v * gm - ma - h * mb);
+            if (silu) { const float pre = h * gm[e] + bt[e]; const float sgm = 1.0f / (1.0f + __expf(-pre)); v *= sgm * (1.0f + pre * (1.0f - sgm)); }
+            d[e] = rstd[e] * (v * gm[e] - ma[e] - h * mb[e]);
         }
-        T* dst = c < C0 ? dx0 + bp * C0 + c : dx1 + bp * C1 + (c - C0);
-        if (c < C0 ? acc0 : acc1) {
+        T* dst = dp + bp * ds;
+        if (acc) {
             float o[VEC];
             TI<T>::unpack(*(const uint4*)dst, o);
 #pragma unroll
@@ -418,9 +424,14 @@ static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, 
                        bta, mr, silu, partial);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, B), dim3(256), 0, s, partial, nslab, B, C, HW, g, dgp, dbp, mab);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, dgp, dbp, B, C, dgamma, dbeta, acc_param);
-    const long long nvec = (long long)B * HW * cols;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(nblk(nvec, 256)), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nvec, (const T*)dy, g, bta, mr, mab,
-                       silu, (T*)dx0, acc0, (T*)dx1, acc1);
+    {
+        const int cblocks = (cols + 255) / 256;
+        const int rows = 256 / (cols < 256 ? cols : 256);
+        int chunks = (HW + rows * 4 - 1) / (rows * 4);            // ~four vectors per thread
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks, B, cblocks), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, (const T*)dy, g, bta, mr, mab,
+                           silu, (T*)dx0, acc0, (T*)dx1, acc1);
+    }
 }
 
 static int kalign(int dtype) { return dtype == WDM_BF16 ? 32 : 16; }
