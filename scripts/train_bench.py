@@ -53,7 +53,7 @@ def main():
         rows = sorted(_lib.prof_report(), key=lambda e: -e["ms"])
         _lib.prof_enable(False)
         tot = sum(e["ms"] for e in rows)
-        for e in rows[:60]:
+        for e in rows[:80]:
             print(f"[shape] {e['kernel']:<72s} n {e['launches']:4d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  "
                   f"{(e['flops'] / e['ms'] / 1e9 if e['ms'] else 0):7.1f} TFLOP/s  {100 * e['ms'] / tot:5.1f}%", file=sys.stderr)
         out["profiled_conv_ms"] = tot

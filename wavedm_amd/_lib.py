@@ -177,9 +177,9 @@ def env_generation() -> int:
 
 def prof_report():
     """-> list of dicts {kernel, launches, ms, flops, bytes} aggregated since the last report."""
-    arr = (ProfEntry * 64)()
+    arr = (ProfEntry * 512)()
     n = C.c_int()
-    check(lib().wdm_prof_report(arr, 64, C.byref(n)))
+    check(lib().wdm_prof_report(arr, 512, C.byref(n)))
     return [dict(kernel=arr[k].kernel.decode(), launches=int(arr[k].launches), ms=float(arr[k].total_ms),
                  flops=float(arr[k].total_flops), bytes=float(arr[k].total_bytes)) for k in range(n.value)]
 

@@ -163,17 +163,19 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid,
             uint4 af[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a_off[ks] + i * (16 * 128));
+            constexpr int NB = WN < 4 ? WN : 4;          // weight fragments held at a time
+            static_assert(WN % NB == 0, "column fragments in groups of four (or all of them)");
 #pragma unroll
-            for (int h = 0; h < WN / 4; ++h) {
-                uint4 bfr[4];
+            for (int h = 0; h < WN / NB; ++h) {
+                uint4 bfr[NB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bfr[j] = *(const uint4*)(base + b_off[ks] + (h * 4 + j) * (16 * 128));
+                for (int j = 0; j < NB; ++j) bfr[j] = *(const uint4*)(base + b_off[ks] + (h * NB + j) * (16 * 128));
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (WDM_GABL & 2) acc[i][h * 4 + j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
-                        else mma16t<T>(acc[i][h * 4 + j], af[i], bfr[j]);
+                    for (int j = 0; j < NB; ++j) {
+                        if (WDM_GABL & 2) acc[i][h * NB + j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
+                        else mma16t<T>(acc[i][h * NB + j], af[i], bfr[j]);
                     }
             }
         }

@@ -343,14 +343,16 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __re
 }
 __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ dgam_part, const float* __restrict__ dbet_part, int B, int C,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    // eight lanes per (parameter, channel): image b goes to lane b % 8, ascending within a lane, then a fixed xor tree (64 dependent loads in one thread were 16 us)
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 3, part = threadIdx.x & 7;
+    const bool live = i < 2 * C;
     const int c = i < C ? i : i - C;
     const float* src = i < C ? dgam_part : dbet_part;
-    float* out = i < C ? dgamma : dbeta;
     float t = 0.f;
-    for (int b = 0; b < B; ++b) t += src[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + t : t;
+    if (live) for (int b = part; b < B; b += 8) t += src[(long long)b * C + c];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) t += __shfl_xor(t, o);
+    if (live && part == 0) { float* out = i < C ? dgamma : dbeta; out[c] = accumulate ? out[c] + t : t; }
 }
 // elementwise over (image, pixel, 16-byte channel vector).  grid (pixel chunks, B, column blocks): a thread keeps ONE channel vector -- its group statistics,
 // gamma and beta live in registers, and no index in the pixel loop divides by a run-time value (the first form did eleven such divisions per vector and ran
@@ -423,7 +425,7 @@ static void l_gn_act_bwd(hipStream_t s, int B, const void* x0, int xs0, int C0, 
     hipLaunchKernelGGL(gn_bwd_sums_kernel<T>, dim3(nslab, B, (cols + 255) / 256), dim3(256), 0, s, (const T*)x0, xs0, C0, (const T*)x1, xs1, C, HW, nslab, (const T*)dy, g,
                        bta, mr, silu, partial);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(32, B), dim3(256), 0, s, partial, nslab, B, C, HW, g, dgp, dbp, mab);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, dgp, dbp, B, C, dgamma, dbeta, acc_param);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * C * 8 + 255) / 256), dim3(256), 0, s, dgp, dbp, B, C, dgamma, dbeta, acc_param);
     {
         const int cblocks = (cols + 255) / 256;
         const int rows = 256 / (cols < 256 ? cols : 256);
