@@ -17,7 +17,8 @@ constexpr int GN_INLINE_MAX_BYTES = 24 * 1024;        // scratch: the second hal
 constexpr int GN_INLINE_MAX_NSLAB = 16;               // measured (batch 64): +1.2 ... 1.7 us per launch at 4 / 16 slabs (16 x 16 / 32 x 32 maps) against the ~7 us of a
                                                       // gn_finalize launch and its boundary; at 64 slabs (64 x 64 maps: 24 KB of partials, +2.3 us per table) +9.3 us per
                                                       // launch with a table per tile (round 3), level with gn_finalize with a table per image (round 4, persistent kernel
-                                                      // walking an image's tiles back to back): those keep gn_finalize
+                                                      // walking an image's tiles back to back) and again level with it on the 512 x 128 tile (two tables per CU: 611.2 / 611.1 / 611.6 img/s with the launches,
+                                                      // 613.6 / 609.3 / 610.1 without): those keep gn_finalize
 __host__ __device__ inline bool gn_inline_shape_ok(int cin, int nslab) {
     return (cin == 128 || cin == 256 || cin == 512) && nslab >= 1 && nslab <= GN_INLINE_MAX_NSLAB && nslab * 384 <= GN_INLINE_MAX_BYTES;
 }
