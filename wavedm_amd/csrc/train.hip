@@ -8,8 +8,10 @@
 //     reduction over b writes the OIHW gradient.  Deterministic: no atomics.
 //   * bias gradients and the per-image temb gradients are fixed-order column sums.
 #include <algorithm>
+#include <atomic>
 
 #include "common.h"
+#include "conv_wgrad_kernel.h"
 
 namespace wdm {
 
@@ -640,6 +642,51 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     }
     const int S = c.B / Bg;
     int rc = WDM_OK;
+    // 3x3 stride-1 layers on 16-pixel-wide maps, bf16: the direct kernel (conv_wgrad_kernel.h) -- no transposed copies, one launch + the partial reduction
+    if (shifted && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && W % 16 == 0 && H % 8 == 0 && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
+        (!s1 || (s0->C % 64 == 0 && s1->xs % 8 == 0)) && cin % 8 == 0) {
+        WgradArgs w{};
+        w.dy = dy.p; w.x0 = s0->p; w.x1 = s1 ? s1->p : nullptr;
+        w.B = c.B; w.H = H; w.W = W; w.cout = cout; w.C0 = s0->C; w.C1 = s1 ? s1->C : 0; w.xs0 = s0->xs; w.xs1 = s1 ? s1->xs : 0; w.cin = cin; w.rows_g = rows_g;
+        w.n_co = (cout + 127) / 128; w.n_ci = (cin + 63) / 64;
+        w.nchunk = c.B * (H / 8) * (W / 16);
+        const int ntile = w.n_co * w.n_ci;
+        int Sd = (256 + ntile - 1) / ntile;                       // one workgroup per CU: the pixels are split as far as the tiles leave CUs idle
+        if (Sd > w.nchunk) Sd = w.nchunk;
+        w.cps = (w.nchunk + Sd - 1) / Sd;
+        w.S = (w.nchunk + w.cps - 1) / w.cps;
+        const size_t px = (size_t)c.B * H * W;
+        w.dy_bytes = (unsigned)(px * cout * es); w.x0_bytes = (unsigned)(px * s0->xs * es); w.x1_bytes = s1 ? (unsigned)(px * s1->xs * es) : 0u;
+        float* part = (float*)c.ar->alloc((size_t)9 * w.S * rows_g * cin * sizeof(float));
+        if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad partials)");
+        w.part = part;
+        if (!c.dry) {
+            if (db || dtemb) {
+                float* per_img = dtemb; int ld = dtemb_ld;
+                if (!per_img) { per_img = (float*)c.ar->alloc((size_t)c.B * cout * sizeof(float)); ld = cout; if (!per_img) WDM_FAIL(WDM_ENOMEM, "workspace too small (bias gradient)"); }
+                WDM_TRY(colsum(c, dy, per_img, true, false, ld));
+                if (db) hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64, 1), dim3(256), 0, c.s, per_img, ld, cout, c.B, 1, db, cout, 0);
+                if (!dtemb) c.ar->free(per_img);
+            }
+            {   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: once per (kernel, device)
+                static std::atomic<unsigned> devs{0};
+                int dev = 0;
+                WDM_HIP(hipGetDevice(&dev));
+                const unsigned bit = 1u << (dev & 31);
+                if (!(devs.load(std::memory_order_acquire) & bit)) {
+                    WDM_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgradCfg::LDS_BYTES));
+                    devs.fetch_or(bit, std::memory_order_release);
+                }
+            }
+            hipLaunchKernelGGL(conv_wgrad_kernel, dim3(w.S * ntile), dim3(WgradCfg::NTHREADS), WgradCfg::LDS_BYTES, c.s, w);
+            const long long total = (long long)9 * cout * cin;
+            hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, 9, w.S, rows_g, cout, cin, dw, accumulate ? 1 : 0);
+            WDM_HIP(hipGetLastError());
+        }
+        c.ar->free(part);
+        if (t_up0) c.ar->free(t_up0);
+        return WDM_OK;
+    }
     if (shifted) {
         // 3x3 stride 1: ONE transposed image per dx column on a grid of (H + 2) rows x Wq columns (Wq = W rounded up to 8, so that a
         // dy tap is a 16-byte aligned shift of +-Wq elements): aT_dx[ci][(y+1) Wq + x] = a[y][x + dx - 1], dyT on the same grid with
