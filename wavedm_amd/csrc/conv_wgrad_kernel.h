@@ -51,8 +51,50 @@ __device__ __forceinline__ unsigned long long wg_tr(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
-// the reads above are invisible to the compiler's wait-count bookkeeping: a fragment is used only after it went through this
-__device__ __forceinline__ void wg_wait(unsigned long long& a, unsigned long long& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+// The reads above are invisible to the compiler's wait-count bookkeeping: a fragment is used only after it went through one of these (LDS reads return in
+// order: lgkmcnt(N) = everything but the N youngest has landed).  The "+v" operands pin the registers between the read and the wait and order the MFMAs behind it.
+template <int N>
+__device__ __forceinline__ void wg_wait2(unsigned long long& a, unsigned long long& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wg_wait10(unsigned long long (&l)[4], unsigned long long (&h)[4], unsigned long long& a, unsigned long long& b) {
+    asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+__device__ __forceinline__ uint4 wg_frag(unsigned long long lo, unsigned long long hi) { return uint4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)}; }
+
+// One k-step (32 pixels = two image rows of the chunk), software-pipelined: on entry the four dy fragments and the x fragment of tap 0 are in flight; every
+// tap requests the next tap's fragment before it waits for its own; the last tap requests the next k-step's first five (not across a chunk boundary:
+// the next chunk's buffer is published by a barrier).
+template <int KS>
+__device__ __forceinline__ void wg_kstep(f32x4 (&acc)[9][4], const unsigned (&aa)[4], const unsigned (&ba)[3][2][2], unsigned so, unsigned long long (&al)[4],
+                                         unsigned long long (&ah)[4], unsigned long long& b0l, unsigned long long& b0h) {
+    uint4 af[4];
+    unsigned long long bl = b0l, bh = b0h, nl = 0, nh = 0;
+#define WDM_WG_TAP(T)                                                                                                                              \
+    do {                                                                                                                                            \
+        constexpr int ty = (T) / 3, dx = (T) % 3, ty1 = ((T) + 1) / 3, dx1 = ((T) + 1) % 3;                                                         \
+        if ((T) < 8) {                                                                                                                              \
+            nl = wg_tr<KS * 6144 + ty1 * 3072>(ba[dx1][0][ty1 & 1] + so);                                                                           \
+            nh = wg_tr<KS * 6144 + ty1 * 3072>(ba[dx1][1][ty1 & 1] + so);                                                                           \
+        } else if (KS < 3) {                                                                                                                        \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) { al[m] = wg_tr<(KS + 1) * 8192>(aa[m] + so); ah[m] = wg_tr<(KS + 1) * 8192 + 1024>(aa[m] + so); } \
+            nl = wg_tr<(KS + 1) * 6144>(ba[0][0][0] + so);                                                                                          \
+            nh = wg_tr<(KS + 1) * 6144>(ba[0][1][0] + so);                                                                                          \
+        }                                                                                                                                           \
+        if ((T) == 0) {                                                                                                                             \
+            wg_wait10<2>(al, ah, bl, bh);                                                                                                           \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) af[m] = wg_frag(al[m], ah[m]);                                                            \
+        } else if ((T) < 8) wg_wait2<2>(bl, bh);                                                                                                    \
+        else if (KS < 3) wg_wait2<10>(bl, bh);                                                                                                      \
+        else wg_wait2<0>(bl, bh);                                                                                                                   \
+        const uint4 bf = wg_frag(bl, bh);                                                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) mma16<__bf16>(acc[ty * 3 + dx][m], af[m], bf);                                                \
+        bl = nl; bh = nh;                                                                                                                           \
+        (void)dx1;                                                                                                                                  \
+    } while (0)
+    WDM_WG_TAP(0); WDM_WG_TAP(1); WDM_WG_TAP(2); WDM_WG_TAP(3); WDM_WG_TAP(4); WDM_WG_TAP(5); WDM_WG_TAP(6); WDM_WG_TAP(7); WDM_WG_TAP(8);
+#undef WDM_WG_TAP
+    b0l = bl; b0h = bh;
+}
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
     using C = WgradCfg;
@@ -174,37 +216,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < c_end) issue(c + 1, buf ^ 1);
         const unsigned so = (unsigned)(buf * C::STAGE);
+        unsigned long long al[4], ah[4], bl, bh;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            uint4 af[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                unsigned long long lo, hi;
-                if (ks == 0) { lo = wg_tr<0>(a_addr[m] + so); hi = wg_tr<1024>(a_addr[m] + so); }
-                else if (ks == 1) { lo = wg_tr<8192>(a_addr[m] + so); hi = wg_tr<8192 + 1024>(a_addr[m] + so); }
-                else if (ks == 2) { lo = wg_tr<16384>(a_addr[m] + so); hi = wg_tr<16384 + 1024>(a_addr[m] + so); }
-                else { lo = wg_tr<24576>(a_addr[m] + so); hi = wg_tr<24576 + 1024>(a_addr[m] + so); }
-                wg_wait(lo, hi);
-                af[m] = uint4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-            }
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const unsigned b0 = b_addr[dx][0][ty & 1] + so, b1 = b_addr[dx][1][ty & 1] + so;
-                    unsigned long long lo, hi;
-#define WDM_WG_RD(KS, TY) do { lo = wg_tr<(KS) * 6144 + (TY) * 3072>(b0); hi = wg_tr<(KS) * 6144 + (TY) * 3072>(b1); } while (0)
-                    if (ks == 0) { if (ty == 0) WDM_WG_RD(0, 0); else if (ty == 1) WDM_WG_RD(0, 1); else WDM_WG_RD(0, 2); }
-                    else if (ks == 1) { if (ty == 0) WDM_WG_RD(1, 0); else if (ty == 1) WDM_WG_RD(1, 1); else WDM_WG_RD(1, 2); }
-                    else if (ks == 2) { if (ty == 0) WDM_WG_RD(2, 0); else if (ty == 1) WDM_WG_RD(2, 1); else WDM_WG_RD(2, 2); }
-                    else { if (ty == 0) WDM_WG_RD(3, 0); else if (ty == 1) WDM_WG_RD(3, 1); else WDM_WG_RD(3, 2); }
-#undef WDM_WG_RD
-                    wg_wait(lo, hi);
-                    const uint4 bf = uint4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) mma16<__bf16>(acc[ty * 3 + dx][m], af[m], bf);
-                }
-        }
+        for (int m = 0; m < 4; ++m) { al[m] = wg_tr<0>(a_addr[m] + so); ah[m] = wg_tr<1024>(a_addr[m] + so); }
+        bl = wg_tr<0>(b_addr[0][0][0] + so);
+        bh = wg_tr<0>(b_addr[0][1][0] + so);
+        wg_kstep<0>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<1>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<2>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<3>(acc, a_addr, b_addr, so, al, ah, bl, bh);
         buf ^= 1;
     }
 
