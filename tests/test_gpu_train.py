@@ -30,7 +30,7 @@ def conv_backward(w, mode, x, dy, dtype, want_dx=True):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("mode,cin,cout,B,H", [
-    (0, 64, 128, 2, 16), (0, 128, 64, 3, 8), (0, 128, 3, 2, 16), (0, 96, 128, 1, 32), (0, 256, 256, 2, 32), (0, 192, 384, 1, 16), (0, 128, 128, 3, 64), (0, 72, 136, 2, 16),
+    (0, 64, 128, 2, 16), (0, 128, 64, 3, 8), (0, 128, 3, 2, 16), (0, 96, 128, 1, 32), (0, 256, 256, 2, 32), (0, 192, 384, 1, 16), (0, 128, 128, 3, 64), (0, 72, 136, 2, 16), (0, 256, 192, 5, 8), (0, 64, 64, 2, 8),
     (1, 64, 64, 2, 16), (2, 64, 64, 2, 8), (3, 64, 128, 2, 16), (3, 384, 128, 1, 16), (3, 160, 64, 3, 8),
 ])
 def test_conv_backward(dtype, mode, cin, cout, B, H):

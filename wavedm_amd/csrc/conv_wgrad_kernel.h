@@ -35,14 +35,24 @@ struct WgradArgs {
     unsigned dy_bytes, x0_bytes, x1_bytes;
 };
 
+// M8 = false: maps that are multiples of 8 x 16 pixels, chunk = 8 rows x 16 columns of one image, halo 10 x 18 in 24-slot rows.
+// M8 = true: 8 x 8 maps, chunk = TWO images (the same 128 dy rows: row = image * 64 + y * 8 + x, a k-step is four image rows of eight pixels), halo 2 x (10 x 10) in
+// 16-slot rows; the two 16-lane groups of an LDS cycle then read rows R .. R + 3 and R + 16 .. R + 19 (the next image row), so g uses bit 4 where the 16-wide form uses bit 3.
+template <bool M8>
 struct WgradCfg {
     static constexpr int NTHREADS = 512;
     static constexpr int DY_BYTES = 128 * 256;                 // 32 KB
-    static constexpr int XROWS = 10 * 24;                       // 240 halo row slots
-    static constexpr int X_BYTES = XROWS * 128;                 // 30 KB
-    static constexpr int STAGE = DY_BYTES + X_BYTES;            // 62 KB
-    static constexpr int LDS_BYTES = 2 * STAGE;                 // 124 KB
-    static constexpr int PIECES = STAGE / 1024;                 // 62 -> 8 per wave (two idle slots)
+    static constexpr int RS = M8 ? 16 : 24;                     // halo row slots per halo row
+    static constexpr int XROWS = M8 ? 2 * 10 * 16 : 10 * 24;    // 320 | 240 halo row slots
+    static constexpr int X_BYTES = XROWS * 128;                 // 40 | 30 KB
+    static constexpr int STAGE = DY_BYTES + X_BYTES;            // 72 | 62 KB
+    static constexpr int LDS_BYTES = 2 * STAGE;                 // 144 | 124 KB
+    static constexpr int PIECES = STAGE / 1024;                 // 72 | 62
+    static constexpr int NP = (PIECES + 7) / 8;                 // pieces per wave: 9 | 8
+    static constexpr int GBIT = M8 ? 4 : 3;                     // g(R) = ((R >> 1) & 1) + 2 ((R >> GBIT) & 1)
+    // byte offset of k-step ks / tap row ty inside the x halo image (both leave (R >> 1) & 1 alone; a tap row flips bit GBIT, a k-step does not)
+    static constexpr int ks_off(int ks) { return M8 ? ((ks & 1) * 64 + (ks >> 1) * 160) * 128 : ks * 48 * 128; }
+    static constexpr int ty_off(int ty) { return ty * RS * 128; }
 };
 
 template <int OFF>
@@ -64,21 +74,22 @@ __device__ __forceinline__ uint4 wg_frag(unsigned long long lo, unsigned long lo
 // One k-step (32 pixels = two image rows of the chunk), software-pipelined: on entry the four dy fragments and the x fragment of tap 0 are in flight; every
 // tap requests the next tap's fragment before it waits for its own; the last tap requests the next k-step's first five (not across a chunk boundary:
 // the next chunk's buffer is published by a barrier).
-template <int KS>
+template <int KS, bool M8>
 __device__ __forceinline__ void wg_kstep(f32x4 (&acc)[9][4], const unsigned (&aa)[4], const unsigned (&ba)[3][2][2], unsigned so, unsigned long long (&al)[4],
                                          unsigned long long (&ah)[4], unsigned long long& b0l, unsigned long long& b0h) {
+    using C = WgradCfg<M8>;
     uint4 af[4];
     unsigned long long bl = b0l, bh = b0h, nl = 0, nh = 0;
 #define WDM_WG_TAP(T)                                                                                                                              \
     do {                                                                                                                                            \
         constexpr int ty = (T) / 3, dx = (T) % 3, ty1 = ((T) + 1) / 3, dx1 = ((T) + 1) % 3;                                                         \
         if ((T) < 8) {                                                                                                                              \
-            nl = wg_tr<KS * 6144 + ty1 * 3072>(ba[dx1][0][ty1 & 1] + so);                                                                           \
-            nh = wg_tr<KS * 6144 + ty1 * 3072>(ba[dx1][1][ty1 & 1] + so);                                                                           \
+            nl = wg_tr<C::ks_off(KS) + C::ty_off(ty1)>(ba[dx1][0][ty1 & 1] + so);                                                                           \
+            nh = wg_tr<C::ks_off(KS) + C::ty_off(ty1)>(ba[dx1][1][ty1 & 1] + so);                                                                           \
         } else if (KS < 3) {                                                                                                                        \
             _Pragma("unroll") for (int m = 0; m < 4; ++m) { al[m] = wg_tr<(KS + 1) * 8192>(aa[m] + so); ah[m] = wg_tr<(KS + 1) * 8192 + 1024>(aa[m] + so); } \
-            nl = wg_tr<(KS + 1) * 6144>(ba[0][0][0] + so);                                                                                          \
-            nh = wg_tr<(KS + 1) * 6144>(ba[0][1][0] + so);                                                                                          \
+            nl = wg_tr<C::ks_off(KS + 1)>(ba[0][0][0] + so);                                                                                          \
+            nh = wg_tr<C::ks_off(KS + 1)>(ba[0][1][0] + so);                                                                                          \
         }                                                                                                                                           \
         if ((T) == 0) {                                                                                                                             \
             wg_wait10<2>(al, ah, bl, bh);                                                                                                           \
@@ -96,8 +107,10 @@ __device__ __forceinline__ void wg_kstep(f32x4 (&acc)[9][4], const unsigned (&aa
     b0l = bl; b0h = bh;
 }
 
+template <bool M8>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
-    using C = WgradCfg;
+    using C = WgradCfg<M8>;
+    constexpr int NP = C::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,48 +144,54 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr unsigned OOB = 0xFFFFFFF0u;
     constexpr int NONE = -2147483647 - 1;
 
-    // ---- DMA sources of this wave's eight pieces, relative to the chunk's first pixel (chunk-invariant part)
-    // pieces 0 .. 31: dy (4 pixel rows each), 32 .. 61: x halo (8 row slots each), 62, 63: none
-    int rel[8];                 // byte offset relative to the chunk origin (dy: of pixel (y, x); x: of halo pixel (hy - 1, hx - 1)), or NONE: never fetched
-    int hyx[8];                 // x pieces: hy << 8 | hx of this lane's row (validity is per chunk)
+    // ---- DMA sources of this wave's pieces, relative to the chunk's first pixel (chunk-invariant part)
+    // pieces 0 .. 31: dy (4 pixel rows each), 32 .. PIECES - 1: x halo (8 row slots each), the rest: none
+    int rel[NP];                // byte offset relative to the chunk origin (dy: of the row's pixel; x: of the halo pixel), or NONE: never fetched
+    int hyx[NP];                // x pieces: (second image of the chunk) << 16 | hy << 8 | hx of this lane's row (validity is per chunk)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int q = wave * 8 + j;
+    for (int j = 0; j < NP; ++j) {
+        const int q = wave * NP + j;
         rel[j] = NONE; hyx[j] = 0;
         if (q < 32) {
             const int r = 4 * q + (lane >> 4);
-            const int y = r >> 4, x = r & 15;
             const int s16 = lane & 15;
             const int f = (r & 3) + 4 * ((r >> 3) & 1);
             const int b = ((s16 >> 1) - f) & 7;
             const int co = co0 + 16 * b + 8 * (s16 & 1);
-            if (co < a.cout) rel[j] = ((y * a.W + x) * a.cout + co) * 2;
-        } else if (q < 62) {
+            const int pix = M8 ? r : (r >> 4) * a.W + (r & 15);            // pixel index relative to the chunk origin
+            if (co < a.cout) { rel[j] = (pix * a.cout + co) * 2; hyx[j] = M8 ? (r >> 6) << 16 : 0; }
+        } else if (q < C::PIECES) {
             const int R = 8 * (q - 32) + (lane >> 3);
-            const int hy = R / 24, hx = R - hy * 24;
+            const int im = M8 ? R / 160 : 0, Rr = M8 ? R - im * 160 : R;
+            const int hy = Rr / C::RS, hx = Rr - hy * C::RS;
             const int s8 = lane & 7;
-            const int g = ((R >> 1) & 1) + 2 * ((R >> 3) & 1);
+            const int g = ((R >> 1) & 1) + 2 * ((R >> C::GBIT) & 1);
             const int b = ((s8 >> 1) - g) & 3;
             const int ci = cil0 + 16 * b + 8 * (s8 & 1);
-            if (hx < 18 && ci < cx) { rel[j] = (((hy - 1) * a.W + (hx - 1)) * xs + ci) * 2; hyx[j] = (hy << 8) | hx; }
+            const int wpx = M8 ? 8 : a.W;
+            if (hx < (M8 ? 10 : 18) && ci < cx) { rel[j] = ((im * 64 + (hy - 1) * wpx + (hx - 1)) * xs + ci) * 2; hyx[j] = (im << 16) | (hy << 8) | hx; }
         }
     }
     auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
-        const int xbn = a.W >> 4, ybn = a.H >> 3;
-        const int xb = chunk % xbn, t = chunk / xbn;
-        const int yb = t % ybn, img = t / ybn;
-        const int y0 = yb * 8, x0 = xb * 16;
+        int img, y0, x0;
+        if (M8) { img = 2 * chunk; y0 = 0; x0 = 0; }
+        else {
+            const int xbn = a.W >> 4, ybn = a.H >> 3;
+            const int xb = chunk % xbn, t = chunk / xbn;
+            const int yb = t % ybn;
+            img = t / ybn; y0 = yb * 8; x0 = xb * 16;
+        }
         const long long origin = ((long long)img * a.H + y0) * a.W + x0;              // pixel index of the chunk's first pixel
         const unsigned o_dy = (unsigned)(origin * a.cout * 2), o_x = (unsigned)(origin * xs * 2);
         const unsigned base = lds0 + buf * C::STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = wave * 8 + j;
+        for (int j = 0; j < NP; ++j) {
+            const int q = wave * NP + j;
+            const int im = hyx[j] >> 16, hy = (hyx[j] >> 8) & 255, hx = hyx[j] & 255;
             if (q < 32) {
-                dma16(q_dy, base + q * 1024, rel[j] != NONE ? o_dy + (unsigned)rel[j] : OOB);
-            } else if (q < 62) {
-                const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
-                const bool ok = rel[j] != NONE && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+                dma16(q_dy, base + q * 1024, rel[j] != NONE && img + im < a.B ? o_dy + (unsigned)rel[j] : OOB);
+            } else if (q < C::PIECES) {
+                const bool ok = rel[j] != NONE && img + im < a.B && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
                 dma16(q_x, base + C::DY_BYTES + (q - 32) * 1024, ok ? o_x + (unsigned)rel[j] : OOB);
             }
         }
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int kq = lane >> 4, i16 = lane & 15;
     unsigned a_addr[4];         // dy fragment m (co block 16 m of this wave's 64): rows of k-step 0, first half
     {
-        const int r = 16 * (kq >> 1) + 8 * (kq & 1) + (i16 >> 2);
+        const int r = 8 * kq + (i16 >> 2);            // 16-wide chunks: image row kq >> 1, columns 8 (kq & 1) ..; 8 x 8 maps: image row kq
         const int f = (r & 3) + 4 * ((r >> 3) & 1);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -195,8 +214,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int R = (kq >> 1) * 24 + 8 * (kq & 1) + 4 * h + dx + (i16 >> 2);
-            const int g = ((R >> 1) & 1) + 2 * ((R >> 3) & 1);
+            const int R = (M8 ? kq * 16 : (kq >> 1) * 24 + 8 * (kq & 1)) + 4 * h + dx + (i16 >> 2);
+            const int g = ((R >> 1) & 1) + 2 * ((R >> C::GBIT) & 1);
             const unsigned v = lds0 + C::DY_BYTES + (unsigned)(R * 128 + (i16 & 3) * 8);
             b_addr[dx][h][0] = v + (unsigned)(((wave_ci + g) & 3) * 32);
             b_addr[dx][h][1] = v + (unsigned)(((wave_ci + g + 2) & 3) * 32);
@@ -221,10 +240,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradArgs a) {
         for (int m = 0; m < 4; ++m) { al[m] = wg_tr<0>(a_addr[m] + so); ah[m] = wg_tr<1024>(a_addr[m] + so); }
         bl = wg_tr<0>(b_addr[0][0][0] + so);
         bh = wg_tr<0>(b_addr[0][1][0] + so);
-        wg_kstep<0>(acc, a_addr, b_addr, so, al, ah, bl, bh);
-        wg_kstep<1>(acc, a_addr, b_addr, so, al, ah, bl, bh);
-        wg_kstep<2>(acc, a_addr, b_addr, so, al, ah, bl, bh);
-        wg_kstep<3>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<0, M8>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<1, M8>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<2, M8>(acc, a_addr, b_addr, so, al, ah, bl, bh);
+        wg_kstep<3, M8>(acc, a_addr, b_addr, so, al, ah, bl, bh);
         buf ^= 1;
     }
 

@@ -643,13 +643,14 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     const int S = c.B / Bg;
     int rc = WDM_OK;
     // 3x3 stride-1 layers on 16-pixel-wide maps, bf16: the direct kernel (conv_wgrad_kernel.h) -- no transposed copies, one launch + the partial reduction
-    if (shifted && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && W % 16 == 0 && H % 8 == 0 && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
+    const bool map8 = H == 8 && W == 8;
+    if (shifted && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && ((W % 16 == 0 && H % 8 == 0) || map8) && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
         (!s1 || (s0->C % 64 == 0 && s1->xs % 8 == 0)) && cin % 8 == 0) {
         WgradArgs w{};
         w.dy = dy.p; w.x0 = s0->p; w.x1 = s1 ? s1->p : nullptr;
         w.B = c.B; w.H = H; w.W = W; w.cout = cout; w.C0 = s0->C; w.C1 = s1 ? s1->C : 0; w.xs0 = s0->xs; w.xs1 = s1 ? s1->xs : 0; w.cin = cin; w.rows_g = rows_g;
         w.n_co = (cout + 127) / 128; w.n_ci = (cin + 63) / 64;
-        w.nchunk = c.B * (H / 8) * (W / 16);
+        w.nchunk = map8 ? (c.B + 1) / 2 : c.B * (H / 8) * (W / 16);
         const int ntile = w.n_co * w.n_ci;
         int Sd = (256 + ntile - 1) / ntile;                       // one workgroup per CU: the pixels are split as far as the tiles leave CUs idle
         if (Sd > w.nchunk) Sd = w.nchunk;
@@ -674,11 +675,13 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
                 WDM_HIP(hipGetDevice(&dev));
                 const unsigned bit = 1u << (dev & 31);
                 if (!(devs.load(std::memory_order_acquire) & bit)) {
-                    WDM_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgradCfg::LDS_BYTES));
+                    WDM_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WgradCfg<false>::LDS_BYTES));
+                    WDM_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WgradCfg<true>::LDS_BYTES));
                     devs.fetch_or(bit, std::memory_order_release);
                 }
             }
-            hipLaunchKernelGGL(conv_wgrad_kernel, dim3(w.S * ntile), dim3(WgradCfg::NTHREADS), WgradCfg::LDS_BYTES, c.s, w);
+            if (map8) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(w.S * ntile), dim3(512), WgradCfg<true>::LDS_BYTES, c.s, w);
+            else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(w.S * ntile), dim3(512), WgradCfg<false>::LDS_BYTES, c.s, w);
             const long long total = (long long)9 * cout * cin;
             hipLaunchKernelGGL(reduce_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, c.s, part, 9, w.S, rows_g, cout, cin, dw, accumulate ? 1 : 0);
             WDM_HIP(hipGetLastError());
