@@ -75,3 +75,22 @@ def test_resblock_bits(gu, c0, c1, cout, B, H):
     assert torch.isfinite(ys[0]).all()
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
+
+
+@pytest.mark.parametrize("c0,c1,cout,B,H", [(128, 0, 128, 2, 64), (128, 128, 128, 1, 64), (96, 0, 128, 1, 32), (256, 0, 128, 3, 32)])
+def test_resblock_bits_f32x3(gu, c0, c1, cout, B, H):
+    """The f32x3 mode's 512 x 128 tile (conv_dmax3t_kernel.h; needs the block's pre-split weight copy, so it is reached through the ResnetBlock, not the single
+    conv): the bits of conv_dmax3_kernel.h."""
+    cin = c0 + c1
+    shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
+              "temb_proj.bias": (cout,), "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    if cin != cout:
+        shapes["nin_shortcut.weight"] = (cout, cin, 1, 1)
+        shapes["nin_shortcut.bias"] = (cout,)
+    sd = gu.blk_sd("rb", shapes)
+    x0 = gu.seeded((B, c0, H, H), 5)
+    x1 = gu.seeded((B, c1, H, H), 7) if c1 else None
+    t = gu.seeded((B, 512), 6)
+    ys = _modes(lambda: gu.resblock(sd, "rb", x0, x1, t, "f32x3"), modes=("0", "2"))
+    assert torch.isfinite(ys[0]).all()
+    assert torch.equal(ys[0], ys[1])
