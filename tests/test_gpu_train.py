@@ -203,6 +203,47 @@ def test_training_step_full_width_f32():
         assert err <= 2e-3, (k, err)
 
 
+def test_direct_weight_gradient_kernel_on_the_full_model_bf16():
+    """conv_wgrad_kernel.h (bf16: NHWC operands in LDS, transposing reads, nine taps in registers) against the batched-GEMM form of the weight gradient
+    (WDM_WGRAD_BG=2 keeps every layer on it) on the full-width model -- channel-concat inputs, the 8 x 8 maps, the upsample convs: the same bf16 operands and
+    fp32 accumulation in another order, so every weight gradient agrees to ~1e-4 of its scale; loss and all other gradients too."""
+    import os
+    from wavedm_amd import _lib, procedural as P
+    from wavedm_amd.training import Trainer
+    cfg = P.raindrop_wavelet_config()
+    cfg.device = dev()
+    sd = P.procedural_state_dict(cfg, seed=61)
+    x0, e, t = seeded((2, 96, 64, 64), 411).to(dev()), seeded((2, 3, 64, 64), 412).to(dev()), torch.tensor([700, 120])
+
+    def run():
+        tr = Trainer(cfg, dtype="bf16")
+        tr.load_state_dict(sd)
+        loss = float(tr.loss_and_grads(x0, t, e))
+        return loss, {k: v.detach().float().cpu().clone() for k, v in tr.grad_dict().items()}
+    old = os.environ.get("WDM_WGRAD_BG")
+    try:
+        os.environ.pop("WDM_WGRAD_BG", None)
+        _lib.env_refresh()
+        l1, g1 = run()
+        os.environ["WDM_WGRAD_BG"] = "2"
+        _lib.env_refresh()
+        l0, g0 = run()
+    finally:
+        if old is None:
+            os.environ.pop("WDM_WGRAD_BG", None)
+        else:
+            os.environ["WDM_WGRAD_BG"] = old
+        _lib.env_refresh()
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    worst = 0.0
+    for k in g0:
+        scale = max(float(g0[k].abs().max()), 1e-12)
+        err = float((g1[k] - g0[k]).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-3, (k, err)
+    print(f"direct vs GEMM-form weight gradient, worst relative difference over {len(g0)} tensors: {worst:.2e}")
+
+
 def test_train_step_api_and_checkpoint_roundtrip(tmp_path):
     """DenoisingDiffusion_Wavelet.train_step on raw crops: the loss goes down over a few steps on a fixed batch, and the checkpoint the
     trainer writes loads back through --resume (reference dict format) with the EMA weights available."""
