@@ -40,14 +40,19 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 // sample_w (optional, training.use_mse): the objective that is differentiated is mean_b w_b sum (e - out)^2 with w_b = (1 - abar_t) / abar_t,
 // which is the reference's mse_loss = sum (x_tar - x0_pred)^2 (:120, :122; x_tar - x0_pred = (out - e) sqrt((1 - abar) / abar)); the value
 // written to *loss stays the unweighted one the reference prints and returns.
+// Loss and its gradient in two launches: LOSS_WGS workgroups each take a contiguous range of elements (fp64 partial, fixed tree), one more workgroup adds the partials
+// in ascending order.  (One 1 024-thread workgroup over all 786 K elements with three run-time divisions per element took 0.58 ms, 1.8 % of a 64-sample step.)
+constexpr int LOSS_WGS = 256;
 template <typename T>
-__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ out, const float* __restrict__ e, int B, int pc, int HW, T* __restrict__ dout,
-                                                    float* __restrict__ loss, float* __restrict__ out_nchw, const float* __restrict__ sqrt_a,
-                                                    const float* __restrict__ sqrt_1ma) {
-    __shared__ double red[1024];
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ e, int B, int pc, int HW, T* __restrict__ dout,
+                                                   double* __restrict__ partial, float* __restrict__ out_nchw, const float* __restrict__ sqrt_a,
+                                                   const float* __restrict__ sqrt_1ma) {
+    __shared__ double red[256];
     const long long total = (long long)B * HW * pc;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < total ? i0 + per : total;
     double s = 0.0;
-    for (long long id = threadIdx.x; id < total; id += 1024) {
+    for (long long id = i0 + threadIdx.x; id < i1; id += 256) {
         const int c = (int)(id % pc);
         const long long bp = id / pc;
         const long long b = bp / HW;
@@ -62,8 +67,14 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ ou
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 512; o >= 1; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) *loss = (float)(red[0] / (double)B);
+    for (int o = 128; o >= 1; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(64) void loss_final_kernel(const double* __restrict__ partial, int n, int B, float* __restrict__ loss) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *loss = (float)(s / (double)B);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void add_into_kernel(T* __restrict__ dst, const T* __restrict__ src, long long n, int accumulate) {
@@ -169,8 +180,9 @@ template <typename T> static void l_build_input(hipStream_t s, const float* x0, 
     hipLaunchKernelGGL(build_input_kernel<T>, dim3(nb(total, 256)), dim3(256), 0, s, x0, e, sa, s1m, C, HW, c_t0, pc, (T*)x96, total);
 }
 template <typename T> static void l_loss(hipStream_t s, const float* out, const float* e, int B, int pc, int HW, void* dout, float* loss, float* out_nchw,
-                                         const float* sqrt_a, const float* sqrt_1ma) {
-    hipLaunchKernelGGL(loss_kernel<T>, dim3(1), dim3(1024), 0, s, out, e, B, pc, HW, (T*)dout, loss, out_nchw, sqrt_a, sqrt_1ma);
+                                         const float* sqrt_a, const float* sqrt_1ma, double* partial) {
+    hipLaunchKernelGGL(loss_kernel<T>, dim3(LOSS_WGS), dim3(256), 0, s, out, e, B, pc, HW, (T*)dout, partial, out_nchw, sqrt_a, sqrt_1ma);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, LOSS_WGS, B, loss);
 }
 // transposed copy used by the attention backward: dst[b][c][n] = src[b][n][c]   (train.hip's gather with stride 1, offset 0)
 int transpose_tokens(Ctx& c, const void* src, int N, int Cc, void* dst);
@@ -539,7 +551,12 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     // ---- loss and its gradient
     void* dout = cc.ar->alloc((size_t)B * R * R * pc * es);
     if (!dout) WDM_FAIL(WDM_ENOMEM, "training workspace too small (loss gradient)");
-    BYT(cc.dtype, l_loss, cc.s, outf, e, B, pc, R * R, dout, loss, out_nchw, use_mse ? sa : nullptr, use_mse ? s1m : nullptr);
+    {
+        double* lpart = (double*)cc.ar->alloc(LOSS_WGS * sizeof(double));
+        if (!lpart) WDM_FAIL(WDM_ENOMEM, "training workspace too small (loss partials)");
+        if (!cc.dry) BYT(cc.dtype, l_loss, cc.s, outf, e, B, pc, R * R, dout, loss, out_nchw, use_mse ? sa : nullptr, use_mse ? s1m : nullptr, lpart);
+        cc.ar->free(lpart);
+    }
     // ---- backward: conv_out by hand, then the tape in reverse
     {
         Tens dy; dy.p = dout; dy.C = pc; dy.H = R; dy.W = R; dy.xs = pc;
