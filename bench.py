@@ -35,11 +35,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+JSON_OUT = None          # the descriptor the one JSON line goes to (main() moves everything else that targets fd 1 to stderr)
+
+
 def fail(msg, n_gpus, rank=0):
     """A run that cannot start still answers with ONE JSON line on rank 0 (value null), then a non-zero exit."""
     if rank == 0:
         print(json.dumps({"metric": "restored images/sec, raindrop 64x64 patches, 100-step DDIM", "value": None, "unit": "img/s",
-                          "n_gpus": n_gpus, "error": msg}), file=sys.__stdout__, flush=True)
+                          "n_gpus": n_gpus, "error": msg}), file=JSON_OUT or sys.__stdout__, flush=True)
     log(f"[bench] {msg}")
     sys.exit(2)
 
@@ -78,6 +81,12 @@ def main():
     args = ap.parse_args()
     # stdout carries the ONE JSON line and nothing else: whatever the libraries underneath print (the restore() front end mirrors the reference's
     # console messages) goes to stderr
+    # -- at the file-descriptor level too: native libraries (gloo's "connected to peer ranks", RCCL with NCCL_DEBUG) write to fd 1 directly
+    global JSON_OUT
+    if JSON_OUT is None and ("RANK" in os.environ or args.gpus == 1):
+        sys.__stdout__.flush()
+        JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     sys.stdout = sys.stderr
 
     backend = os.environ.get("WAVEDM_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only to smoke-test the N > 1 code path on one GPU
@@ -528,7 +537,7 @@ def main():
                            "rank_elapsed_s_min": round(min(rank_elapsed), 4), "rank_elapsed_s_max": round(max(rank_elapsed), 4)}
         if cpu:
             res["speedup_vs_cpu"] = round(res["value"] / cpu["value"], 1)
-        print(json.dumps(res), file=sys.__stdout__, flush=True)
+        print(json.dumps(res), file=JSON_OUT or sys.__stdout__, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
