@@ -661,7 +661,8 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     int rc = WDM_OK;
     // 3x3 stride-1 layers on 16-pixel-wide maps, bf16: the direct kernel (conv_wgrad_kernel.h) -- no transposed copies, one launch + the partial reduction
     const bool map8 = H == 8 && W == 8;
-    if (shifted && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && ((W % 16 == 0 && H % 8 == 0) || map8) && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
+    const bool fits32 = (unsigned long long)c.B * H * W * (unsigned long long)std::max(std::max(cout, s0->xs), s1 ? s1->xs : 0) * 2ull < (1ull << 32);      // buffer offsets are 32-bit
+    if (shifted && fits32 && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && ((W % 16 == 0 && H % 8 == 0) || map8) && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
         (!s1 || (s0->C % 64 == 0 && s1->xs % 8 == 0)) && cin % 8 == 0) {
         WgradArgs w{};
         w.dy = dy.p; w.x0 = s0->p; w.x1 = s1 ? s1->p : nullptr;
