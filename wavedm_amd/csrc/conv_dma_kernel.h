@@ -58,7 +58,8 @@ struct ConvDmaCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// PACKED: the launcher's conv_epilogue_can_pack(a) && no in-tile GroupNorm of the output (one epilogue form per instantiation: fewer live registers, no run-time test)
+// PACKED: the launcher's conv_epilogue_can_pack(a) (one epilogue form per instantiation: fewer live registers, no run-time test); both forms can also write the
+// consumer's act(GroupNorm(y)) from their LDS tiles (ConvArgs::yn, 16 x 16 maps)
 template <bool PACKED>
 __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     using C = ConvDmaCfg;
@@ -357,9 +358,15 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     // 16 x 16 maps: the tile is one whole image x BN columns -- the consumer's act(GroupNorm(y)) from here when it asked for it (gn_group.h; host check)
     using G = GnTailGeom<16, TW, 4, WN, WN, C::WAVES_N>;
     static_assert(G::total_bytes(C::NWAVES, 1, C::BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
-    float4* keep_tab = (!PACKED && a.yn != nullptr) ? (float4*)(smem + G::tiles_bytes(C::NWAVES)) : nullptr;
+    // (bf16-tile epilogue: eight 8 KB tiles, the table behind them)
+    constexpr int KEEP_OFF = PACKED ? C::NWAVES * EPI_PACK_TILE : G::tiles_bytes(C::NWAVES);
+    float4* keep_tab = a.yn != nullptr ? (float4*)(smem + KEEP_OFF) : nullptr;
     conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, (PACKED ? 2 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, C::BN);
-    if (!PACKED && a.yn != nullptr) gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, C::BN>(a, img0, 1, n0, smem, keep_tab, (float*)(smem + G::tiles_bytes(C::NWAVES) + G::keep_bytes(1, C::BN)), tid);
+    if (a.yn != nullptr) {
+        float* tab = (float*)(smem + KEEP_OFF + G::keep_bytes(1, C::BN));
+        if constexpr (PACKED) gn_out_tail_packed<C::NTHREADS, C::WAVES_N, C::BN>(a, img0, n0, smem, keep_tab, tab, tid);
+        else gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, C::BN>(a, img0, 1, n0, smem, keep_tab, tab, tid);
+    }
     gn_arrive<C::NTHREADS>(a, img0, 1, a.Hout * a.Wout, (int*)smem, tid);       // the consumer's GroupNorm finalised by the image's last workgroup (when asked: fin_cnt)
 #ifdef WDM_WG_CLOCK
     if (threadIdx.x == 0) { a.ts[512 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); a.ts[512 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); }

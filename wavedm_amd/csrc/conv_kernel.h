@@ -662,7 +662,7 @@ __host__ __device__ __forceinline__ bool conv_epilogue_can_pack(const AT& a) {
 constexpr int EPI_PACK_TILE = 64 * 128;      // LDS bytes per wave
 template <int TH, int TW, int WN, class Hook = EpiNoHook, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4][WN], int jp, char* smem, int wave, int lane_, int wave_m, int wave_n, int img0, int oy0,
-                                                     int ox0, int n0, int tile_in_img, int phase, Hook hook, bool call_hook) {
+                                                     int ox0, int n0, int tile_in_img, int phase, Hook hook, bool call_hook, float4* keep_tab = nullptr, int keep_bn = 0) {
     constexpr int EROWS = 64, ROWB = 128;
     int lane = lane_;
     asm volatile("" : "+v"(lane));             // every address below is a function of the lane: formed HERE, not hoisted above the K loop (where ~40 of them would
@@ -756,6 +756,8 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
         const int slab = tile_in_img * SPT + (m0 % (TH * TW)) / 64 + (a.up4 ? phase * (a.stats_nslab >> 2) : 0);
         const int nn = ncol0 + col;
         if (nn < a.Cout && img_g < a.B) conv_store_stat(a, ((long long)img_g * a.stats_nslab + slab) * a.Cout + nn, make_float4(K, s1, s2, 64.f));
+        // (in-tile GroupNorm of the output, gn_group.h: gn_out_tail_packed -- the tile's own table of these partials, as conv_epilogue_w keeps it)
+        if (keep_tab != nullptr && nn < a.Cout) keep_tab[((m0 / (TH * TW)) * SPT + (m0 % (TH * TW)) / 64) * keep_bn + (nn - n0)] = make_float4(K, s1, s2, 64.f);
         if (a.gst != nullptr) {
             const int gs = a.Cout >> 5;
             const float Kg = __shfl(K, lane & ~(gs - 1));
@@ -787,7 +789,7 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
             if (entry_barrier) __syncthreads();
 #pragma unroll
             for (int jp = 0; jp < WN; jp += 4)
-                conv_epilogue_packed<TH, TW, WN, Hook, AT>(a, acc, jp, smem, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, jp == 0);
+                conv_epilogue_packed<TH, TW, WN, Hook, AT>(a, acc, jp, smem, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, jp == 0, keep_tab, keep_bn);
             return;
         }
     }

@@ -180,4 +180,40 @@ __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int
     }
 }
 
+// The same tail behind the bf16-tile epilogue (conv_epilogue_packed; 16 x 16 maps on 256 x 128 tiles: ONE image x 128 columns, one pass): wave (wm, wn) keeps its 64 rows x
+// 64 columns as the swizzled bf16 tile of that epilogue -- row r = 128 bytes, 16-byte unit u in slot u ^ (r & 7), the unit's 8-byte halves swapped when r & 8 --,
+// i.e. exactly the values stored to y; statistics table, group reduction and per-element arithmetic are those of gn_out_tail: the same bits.
+template <int NTHREADS, int WAVES_N, int BN, class AT>
+__device__ __forceinline__ void gn_out_tail_packed(const AT& a, int img0, int n0, char* smem, const float4* keep_tab, float* tab, int tid) {
+    using T = __bf16;
+    constexpr int NW = NTHREADS / 64, HW = 256, SPT = 4, bn = BN;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int gw = a.Cout >> 5;
+    const int ng = BN / gw;
+    __syncthreads();                                        // the tiles and keep_tab are complete
+    for (int p = wave; p < ng; p += NW) {
+        float gam = 0.f, bet = 0.f;
+        if (lane < gw) { gam = a.on_gamma[n0 + p * gw + lane]; bet = a.on_beta[n0 + p * gw + lane]; }
+        float mean, rstd;
+        gn_group_stats(keep_tab, SPT, bn, keep_tab, 1, 32 * gw, HW, a.on_eps, p, 0, lane, mean, rstd);
+        if (lane < gw) gn_scale_shift(mean, rstd, gam, bet, tab[p * gw + lane], tab[bn + p * gw + lane]);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_n = __builtin_amdgcn_make_buffer_rsrc(a.yn, 0, (int)(unsigned)((long long)a.B * HW * a.Cout * 2), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int cols = BN / 8;                            // 16-byte units per pixel
+#pragma unroll
+    for (int id = tid; id < HW * cols; id += NTHREADS) {
+        const int cu = id % cols, m = id / cols;            // unit, pixel (= row of the workgroup's tile)
+        const int wm = m >> 6, r = m & 63, wn = cu >> 3, u = cu & 7;
+        uint4 v = *(const uint4*)(smem + (wm * WAVES_N + wn) * 8192 + r * 128 + ((u ^ (r & 7)) << 4));
+        if (r & 8) v = uint4{v.z, v.w, v.x, v.y};
+        float f[8];
+        TI<T>::unpack(v, f);
+        const int col = cu * 8;
+        const uint4 o = gn_apply_f8<T>(f, &tab[col], &tab[bn + col], a.on_silu);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_n, (int)(unsigned)((((long long)img0 * HW + m) * a.Cout + n0 + col) * 2), 0, WDM_STORE_AUX);
+    }
+}
+
 }  // namespace wdm
