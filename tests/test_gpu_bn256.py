@@ -77,9 +77,10 @@ def test_resblock_bits(gu, c0, c1, cout, B, H):
         assert torch.equal(ys[0], y)
 
 
-@pytest.mark.parametrize("c0,c1,cout,B,H", [(128, 0, 128, 2, 64), (128, 128, 128, 1, 64), (96, 0, 128, 1, 32), (256, 0, 128, 3, 32)])
+@pytest.mark.parametrize("c0,c1,cout,B,H", [(128, 0, 128, 2, 64), (128, 128, 128, 1, 64), (96, 0, 128, 1, 32), (256, 0, 128, 3, 32), (256, 0, 256, 2, 32),
+                                            (256, 256, 256, 1, 32), (128, 0, 256, 3, 16)])
 def test_resblock_bits_f32x3(gu, c0, c1, cout, B, H):
-    """The f32x3 mode's 512 x 128 tile (conv_dmax3t_kernel.h; needs the block's pre-split weight copy, so it is reached through the ResnetBlock, not the single
+    """The f32x3 mode's 512 x 128 and 256 x 256 tiles (conv_dmax3t_kernel.h; they need the block's pre-split weight copy, so it is reached through the ResnetBlock, not the single
     conv): the bits of conv_dmax3_kernel.h."""
     cin = c0 + c1
     shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),

@@ -78,7 +78,7 @@ class AsyncImageWriter:
 
     def __init__(self, max_pending: int = 64, workers: int = 0):
         self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
-        n = workers if workers > 0 else max(1, min(8, (os.cpu_count() or 2) // 2))
+        n = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 4))
         self._threads = [threading.Thread(target=self._run, name=f"wavedm-png-writer-{k}", daemon=True) for k in range(n)]
         self._stream = None
         self._errors = []
