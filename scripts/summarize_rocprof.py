@@ -39,6 +39,10 @@ def short(name: str) -> str:
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
     if m:
         return f"convup4_2x2x4_t{m.group(1)}x{m.group(1)}x{m.group(2)}_bn{32 * int(m.group(3) or 4)}w8_bf16"
+    m = re.search(r"conv_dmax3t_kernel(?:ILb(\d)E|<(true|false)>)", name)
+    if m:                                            # round 4: the f32x3 big tiles, <true> = 512 x 128, <false> = 256 x 256
+        tall = m.group(1) == "1" or m.group(2) == "true"
+        return "convdmax3_3x3s1_t32x16x1_bn128w8_f32x3" if tall else "convdmax3_3x3s1_t16x16x1_bn256w8_f32x3"
     if "conv_dmax3_kernel" in name:
         return "convdmax3_3x3s1_t16x16x1_bn128w8_f32x3"
     m = re.search(r"conv_dma8x3_kernelILi(\d+)E", name)
@@ -60,6 +64,9 @@ def short(name: str) -> str:
         return f"convdma8_3x3s1_t8x8x2_bn{m.group(1)}w4_bf16"
     if "attn_fused_kernel" in name:
         return "attn_fused_n256_bf16"
+    m = re.search(r"conv_wgrad_kernelILb(\d)E", name)
+    if m:                                            # training: the direct weight gradient, <true> = 8 x 8 maps
+        return "conv_wgrad_8x8_bf16" if m.group(1) == "1" else "conv_wgrad_bf16"
     m = re.search(r"conv_gemm_kernelI((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
