@@ -12,12 +12,12 @@
 //   <8, 1, 4, 8, 32>  512 pixels (32 x 16) x 128 channels (round 4): the same 64 x 128 wave tile stacked eight high instead of four high and two wide -- for
 //                     layers with ONE 128-column N tile and several rounds of 256-pixel tiles (the 64 x 64 maps: 1 024 tiles -> 512): per MFMA half the
 //                     weight DMA, weight fragment reads and barriers of the 256 x 128 kernel, a 34 x 18 halo instead of two 18 x 18 ones
-// Both accumulate a pixel's K in the order of conv_dma_kernel.h (slab, dx, dy) and hand each 64-pixel wave tile to the same epilogue at the position
+// All accumulate a pixel's K in the order of conv_dma_kernel.h (slab, dx, dy) and hand each 64-pixel wave tile to the same epilogue at the position
 // it has in the 16 x 16 tiling, so outputs AND GroupNorm partial statistics are bit-identical to the 128-column kernel: the launcher may choose by
 // workgroup count (tests/test_gpu_bn256.py).
 //
 // LDS (160 KB): A[2] halo slabs (2 x 24 KB | 2 x 16 KB), weight ring of TWO dx columns (2 x 48 KB: 3 taps x 256 rows x 64 B) at 48 KB | 32 KB,
-// scale/shift table at 144 KB.  A column is requested right behind the barrier that frees its slot and waited for before the next one: one
+// scale/shift table at 144 KB; the 512 x 128 tile: 2 x 40 KB, a ring of THREE 24 KB columns at 80 KB (two sub-stages of lead), table (Cin <= 1024) at 152 KB.  A column is requested right behind the barrier that frees its slot and waited for before the next one: one
 // sub-stage (96 | 48 MFMAs per wave) of lead.  Per wave and sub-stage: 6 weight pieces (+ 3 | 2 halo pieces once per slab).
 #pragma once
 #include "conv_kernel.h"
