@@ -244,6 +244,25 @@ def test_direct_weight_gradient_kernel_on_the_full_model_bf16():
     print(f"direct vs GEMM-form weight gradient, worst relative difference over {len(g0)} tensors: {worst:.2e}")
 
 
+def test_training_gradients_are_deterministic_bf16():
+    """No atomics anywhere in the backward (the direct weight-gradient kernel reduces its split-K partials in a fixed order): two runs of the same full-width
+    step give the same loss and the same gradient bits."""
+    from wavedm_amd import procedural as P
+    from wavedm_amd.training import Trainer
+    cfg = P.raindrop_wavelet_config()
+    cfg.device = dev()
+    sd = P.procedural_state_dict(cfg, seed=61)
+    x0, e, t = seeded((3, 96, 64, 64), 421).to(dev()), seeded((3, 3, 64, 64), 422).to(dev()), torch.tensor([900, 40, 511])
+    tr = Trainer(cfg, dtype="bf16")
+    tr.load_state_dict(sd)
+    l0 = float(tr.loss_and_grads(x0, t, e))
+    g0 = tr.grads.clone()
+    for _ in range(2):
+        l1 = float(tr.loss_and_grads(x0, t, e))
+        assert l1 == l0
+        assert torch.equal(tr.grads, g0)
+
+
 def test_train_step_api_and_checkpoint_roundtrip(tmp_path):
     """DenoisingDiffusion_Wavelet.train_step on raw crops: the loss goes down over a few steps on a fixed batch, and the checkpoint the
     trainer writes loads back through --resume (reference dict format) with the EMA weights available."""
