@@ -280,6 +280,15 @@ int wdm_trainer_step(wdm_trainer* t, const float* x0, const float* tt, const flo
                      int B, int c_t0, float* loss, float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
 int wdm_trainer_adam_ema(wdm_trainer* t, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          float ema_mu, void* stream);
+/* Gradient buckets for a data-parallel all-reduce that overlaps the backward (the reference wraps the model in DistributedDataParallel, ddm_wavelet.py:168,
+ * which all-reduces 25 MB buckets while the backward runs).  The parameters sit in the flat buffers in forward order and the backward runs in reverse, so the
+ * gradient buffer fills from its end: with n events set (hipEvent_t handles owned by the caller; n = 0 switches the feature off) every following
+ * wdm_trainer_step cuts the filled range into at most n buckets of about equal size and records event k on the step's stream behind the last launch that
+ * writes bucket k.  wdm_trainer_grad_buckets returns the bounds of the last step in float elements of the gradient buffer, descending:
+ * bucket k = [bounds[k + 1], bounds[k]), 0 <= k < *n_buckets <= n (bounds needs room for n + 1 values).  What lies outside [bounds[n_buckets], bounds[0]) --
+ * the timestep-embedding MLP and the temb_proj matrix -- is final only when the whole step is. */
+int wdm_trainer_set_grad_events(wdm_trainer* t, void* const* events, int n);
+int wdm_trainer_grad_buckets(const wdm_trainer* t, int64_t* bounds, int max_bounds, int* n_buckets);
 
 /* ---- live kernel timing (bench.py roofline leg) ----------------------------------------------
  * While enabled, every convolution launch is bracketed by two HIP events on its own stream and

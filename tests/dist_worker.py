@@ -57,6 +57,15 @@ def main(out_path):
     lo, hi = parallel.shard_range(4, rank, world)
     tr.loss_and_grads(bx[lo:hi].to(dev), bt[lo:hi], be[lo:hi].to(dev))
     tr.allreduce_grads()
+    # ... the same step with the all-reduce in buckets behind events recorded DURING the backward: the same averaged gradients, bit for bit on two ranks
+    trb = Trainer(cfg, dtype="f32")
+    trb.load_state_dict(P.procedural_state_dict(cfg, seed=61))
+    trb.enable_grad_buckets(5)
+    trb.loss_and_grads(bx[lo:hi].to(dev), bt[lo:hi], be[lo:hi].to(dev))
+    trb.allreduce_grads_overlapped()
+    torch.cuda.synchronize()
+    bk = trb.grad_buckets()
+    buckets_ok = len(bk) >= 2 and torch.equal(trb.grads, tr.grads) and all(a[0] == b[1] for a, b in zip(bk[:-1], bk[1:])) and all(lo_ < hi_ for lo_, hi_ in bk)
     tr.optimizer_step()
     # (4) from-scratch training, no --resume: the ranks build DIFFERENT random models (the ADVICE r1 scenario); make_trainer() must leave
     # every rank with rank 0's parameters, as DistributedDataParallel's construction-time broadcast does (ddm_wavelet.py:168)
@@ -82,7 +91,7 @@ def main(out_path):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         torch.save({"out_img": out_img.cpu(), "fresh_init_synced": bool(flag.item() == 1.0), "xs_last": xs[-1].cpu(), "x0_m5": x0[-5].cpu(), "world": world,
-                    "grads": tr.grads.cpu(), "params1": tr.params.cpu()}, out_path)
+                    "grads": tr.grads.cpu(), "params1": tr.params.cpu(), "buckets_ok": bool(buckets_ok), "buckets": bk}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -32,6 +32,7 @@ def run_two_ranks(tmp_path, backend):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out)
     assert got["world"] == 2
+    assert got["buckets_ok"], got["buckets"]                      # bucketed, backward-overlapped all-reduce == the flat one
     assert got["fresh_init_synced"]                                 # from-scratch training starts from rank 0's weights on every rank
     # single-process references
     dev = torch.device("cuda", 0)

@@ -109,6 +109,8 @@ def lib():
         "wdm_trainer_set_objective": (i, [vp, i]),
         "wdm_trainer_step": (i, [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]),
         "wdm_trainer_adam_ema": (i, [vp, i64, f, f, f, f, f, f, vp]),
+        "wdm_trainer_set_grad_events": (i, [vp, C.POINTER(vp), i]),
+        "wdm_trainer_grad_buckets": (i, [vp, C.POINTER(i64), i, C.POINTER(i)]),
         "wdm_dwt_fwd_affine": (i, [vp, vp, f, f, vp, i, i, i, vp]),
         "wdm_dwt_inv_compose": (i, [vp, vp, i, i, vp, vp, i, i, i, i, vp]),
         "wdm_conv2d_direct": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp, vp]),
@@ -137,7 +139,7 @@ EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "w
             "wdm_hfrm_create", "wdm_hfrm_destroy", "wdm_hfrm_num_params", "wdm_hfrm_param_info", "wdm_hfrm_packed_bytes",
             "wdm_hfrm_set_packed", "wdm_hfrm_load_param", "wdm_hfrm_finalize", "wdm_hfrm_workspace_bytes",
             "wdm_hfrm_forward", "wdm_image_sqdiff", "wdm_to_u8_hwc", "wdm_conv_backward", "wdm_gn_act_backward", "wdm_trainer_create", "wdm_trainer_destroy", "wdm_trainer_num_params",
-            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_dwt_fwd_affine", "wdm_dwt_inv_compose", "wdm_conv2d_direct", "wdm_groupnorm", "wdm_cross_attention", "wdm_upsample_add",
+            "wdm_trainer_num_floats", "wdm_trainer_param_info", "wdm_trainer_set_buffers", "wdm_trainer_set_objective", "wdm_trainer_step", "wdm_trainer_adam_ema", "wdm_trainer_set_grad_events", "wdm_trainer_grad_buckets", "wdm_dwt_fwd_affine", "wdm_dwt_inv_compose", "wdm_conv2d_direct", "wdm_groupnorm", "wdm_cross_attention", "wdm_upsample_add",
             "wdm_prof_enable", "wdm_prof_report", "wdm_env_refresh", "wdm_set_concurrent_streams"]
 
 

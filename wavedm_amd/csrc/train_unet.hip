@@ -222,6 +222,10 @@ struct wdm_trainer {
     Ctx* c = nullptr;
     std::deque<TT> acts;
     std::vector<std::function<int()>> tape;
+    std::vector<std::pair<long long, long long>> tape_rng;     // [lo, hi) of the flat gradient buffer a tape entry writes ((-1, -1): none)
+    // gradient buckets for an all-reduce that overlaps the backward (wdm_trainer_set_grad_events): events to record, the bounds of the last step
+    std::vector<hipEvent_t> gev;
+    std::vector<long long> gbounds;
     float* temb_all = nullptr;      // [B][temb_rows] forward values, and its gradient
     float* d_temb_all = nullptr;
 
@@ -333,6 +337,7 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
     cx.ar->free(pk);
     *out = o;
     const ConvP pp = p;
+    tape_rng.push_back({(long long)std::min(pp.w, pp.b), (long long)std::max(pp.w + (size_t)pp.cout * pp.cin * pp.k * pp.k, pp.b + (size_t)pp.cout)});
     tape.push_back([this, pp, mode, x0, x1, temb_row, res, o, wd]() -> int {
         Ctx& cx = *c;
         if (!o->g) WDM_FAIL(WDM_ESTATE, "backward: conv output without gradient");
@@ -388,6 +393,7 @@ int wdm_trainer::op_gn_act(const NormP& p, TT* x0, TT* x1, int silu, TT** out) {
     if (own0) cx.ar->free(st0);
     *out = o;
     const NormP pp = p;
+    tape_rng.push_back({(long long)std::min(pp.g, pp.b), (long long)std::max(pp.g, pp.b) + C});
     tape.push_back([this, pp, x0, x1, silu, o, mr, C]() -> int {
         Ctx& cx = *c;
         if (!o->g) WDM_FAIL(WDM_ESTATE, "backward: GroupNorm output without gradient");
@@ -441,6 +447,7 @@ int wdm_trainer::op_attn(const AttnP& a, TT* x, TT** out) {
     WDM_TRY(transpose_tokens(cx, v->t.p, N, C, vT));
     WDM_TRY(bgemm(Pm, N, vT, C, (long long)C * N, o->t.p, Y_NHWC, 1.f));
     cx.ar->free(vT); cx.ar->free(S);
+    tape_rng.push_back({-1, -1});
     tape.push_back([this, q, k, v, o, Pm, C, N, B, es, scale, x]() -> int {
         Ctx& cx = *c;
         if (!o->g) WDM_FAIL(WDM_ESTATE, "backward: attention output without gradient");
@@ -483,7 +490,7 @@ int wdm_trainer::op_attn(const AttnP& a, TT* x, TT** out) {
 
 int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa, const float* s1m, const float* e, int c_t0, float* loss, float* out_nchw) {
     c = &cc;
-    acts.clear(); tape.clear();
+    acts.clear(); tape.clear(); tape_rng.clear();
     const int nres = cfg.n_levels, nrb = cfg.num_res_blocks, R = cfg.resolution, B = cc.B;
     const size_t es = dsize(cc.dtype);
     auto af = [&](size_t n) -> float* { return (float*)cc.ar->alloc(n * 4); };
@@ -565,7 +572,36 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
         bool f; WDM_TRY(grad_buf(an, &f));
         WDM_TRY(conv_dgrad(cc, MODE_S1, P + conv_out.w, conv_out.cin, pc, dy, R, R, an->g, false));
     }
-    for (size_t i = tape.size(); i-- > 0;) WDM_TRY(tape[i]());
+    // The tape runs in reverse; the parameters sit in the flat buffers in forward order, so the gradient buffer fills from its END.  With events set
+    // (wdm_trainer_set_grad_events) the range finished so far is cut into buckets and an event is recorded behind each: the caller's all-reduce of a bucket
+    // can start while the rest of the backward still runs (the reference's DistributedDataParallel does the same with 25 MB buckets, ddm_wavelet.py:168).
+    // A cut at entry i is valid when no earlier entry writes at or above the running minimum.
+    gbounds.clear();
+    {
+        std::vector<long long> prefix_hi(tape.size() + 1, 0);
+        for (size_t i = 0; i < tape.size(); ++i) prefix_hi[i + 1] = std::max(prefix_hi[i], tape_rng[i].second);
+        long long run_lo = (long long)std::min(conv_out.w, conv_out.b);
+        const long long body_hi = (long long)std::max(conv_out.w + (size_t)pc * conv_out.cin * 9, conv_out.b + (size_t)pc);
+        long long body_lo = run_lo;
+        for (size_t i = 0; i < tape.size(); ++i) if (tape_rng[i].first >= 0) body_lo = std::min(body_lo, tape_rng[i].first);
+        const size_t nev = gev.size();
+        const long long target = nev ? (body_hi - body_lo + (long long)nev - 1) / (long long)nev : 0;
+        long long prev = body_hi;
+        if (nev) gbounds.push_back(body_hi);
+        for (size_t i = tape.size(); i-- > 0;) {
+            WDM_TRY(tape[i]());
+            if (tape_rng[i].first >= 0) run_lo = std::min(run_lo, tape_rng[i].first);
+            if (nev && gbounds.size() < nev && i > 0 && prefix_hi[i] <= run_lo && prev - run_lo >= target) {
+                WDM_HIP(hipEventRecord(gev[gbounds.size() - 1], cc.s));
+                gbounds.push_back(run_lo);
+                prev = run_lo;
+            }
+        }
+        if (nev && prev > run_lo) {
+            WDM_HIP(hipEventRecord(gev[gbounds.size() - 1], cc.s));
+            gbounds.push_back(run_lo);
+        }
+    }
     // ---- temb MLP backward
     {
         const long long n4 = (long long)B * temb_ch;
@@ -585,7 +621,7 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
         l_colsum_f32(cc.s, d_pre0, temb_ch, B, G + d0b, csc);
         WDM_HIP(hipGetLastError());
     }
-    acts.clear(); tape.clear();
+    acts.clear(); tape.clear(); tape_rng.clear();
     return WDM_OK;
 }
 
@@ -626,6 +662,25 @@ int wdm_trainer_set_buffers(wdm_trainer* t, float* params, float* grads, float* 
 int wdm_trainer_set_objective(wdm_trainer* t, int use_mse) {
     if (!t) WDM_FAIL(WDM_EINVAL, "wdm_trainer_set_objective: null trainer");
     t->use_mse = use_mse != 0;
+    return WDM_OK;
+}
+// Gradient buckets (include/wavedm.h): events the next steps record as the flat gradient buffer fills from its end; the bounds of the last step.
+int wdm_trainer_set_grad_events(wdm_trainer* t, void* const* events, int n) {
+    if (!t || n < 0 || n > 64 || (n > 0 && !events)) WDM_FAIL(WDM_EINVAL, "wdm_trainer_set_grad_events: bad argument");
+    t->gev.clear();
+    for (int i = 0; i < n; ++i) {
+        if (!events[i]) WDM_FAIL(WDM_EINVAL, "wdm_trainer_set_grad_events: null event %d", i);
+        t->gev.push_back((hipEvent_t)events[i]);
+    }
+    t->gbounds.clear();
+    return WDM_OK;
+}
+int wdm_trainer_grad_buckets(const wdm_trainer* t, int64_t* bounds, int max_bounds, int* n_buckets) {
+    if (!t || !bounds || !n_buckets) WDM_FAIL(WDM_EINVAL, "wdm_trainer_grad_buckets: null argument");
+    const int nb = t->gbounds.empty() ? 0 : (int)t->gbounds.size() - 1;
+    if ((int)t->gbounds.size() > max_bounds) WDM_FAIL(WDM_EINVAL, "wdm_trainer_grad_buckets: %d bounds do not fit %d", (int)t->gbounds.size(), max_bounds);
+    for (size_t i = 0; i < t->gbounds.size(); ++i) bounds[i] = (int64_t)t->gbounds[i];
+    *n_buckets = nb;
     return WDM_OK;
 }
 int wdm_trainer_step(wdm_trainer* t, const float* x0, const float* tt, const float* sqrt_a, const float* sqrt_1ma, const float* e, int B, int c_t0, float* loss,

@@ -130,6 +130,10 @@ class DenoisingDiffusion_Wavelet(object):
             tr.load_optimizer_state_dict(osd)
             tr.step = self.step = max(tr.step, self.step)
         tr.broadcast_state(src=0)                                               # DDP's construction-time broadcast (ddm_wavelet.py:168)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and os.environ.get("WAVEDM_GRAD_BUCKETS", "8") != "0":
+            # ... and its bucketed gradient all-reduce that overlaps the backward (Trainer.allreduce_grads_overlapped); WAVEDM_GRAD_BUCKETS=0: one flat all-reduce
+            tr.enable_grad_buckets(int(os.environ.get("WAVEDM_GRAD_BUCKETS", "8")))
         self.trainer = tr
         return tr
 

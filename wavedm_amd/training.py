@@ -146,6 +146,57 @@ class Trainer:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
             self.grads.div_(dist.get_world_size(group))              # DDP averages
 
+    # ---- gradient all-reduce in buckets that overlap the backward (what DistributedDataParallel does for the reference, ddm_wavelet.py:168) ----------------
+    def enable_grad_buckets(self, n: int = 8):
+        """The next loss_and_grads calls record an event behind the last launch that writes each of (at most) n buckets of the flat gradient buffer --
+        it fills from its end while the backward runs -- so that allreduce_grads_overlapped can start a bucket's all-reduce before the backward is over.
+        n = 0 switches it off."""
+        import ctypes as C
+        with torch.cuda.device(self.device):
+            self._gev = [torch.cuda.Event() for _ in range(int(n))]
+            for ev in self._gev:
+                ev.record()                                           # torch creates the handle on first use
+            arr = (C.c_void_p * max(1, len(self._gev)))(*[C.c_void_p(int(ev.cuda_event)) for ev in self._gev])
+            _lib.check(_lib.lib().wdm_trainer_set_grad_events(self._t, arr, len(self._gev)))
+            self._comm_stream = torch.cuda.Stream(device=self.device) if self._gev else None
+
+    def grad_buckets(self):
+        """[(lo, hi)] in elements of self.grads, in the order the backward completes them (the last step's cut)."""
+        import ctypes as C
+        n = len(getattr(self, "_gev", []) or [])
+        if n == 0:
+            return []
+        bounds, nb = (C.c_int64 * (n + 1))(), C.c_int()
+        _lib.check(_lib.lib().wdm_trainer_grad_buckets(self._t, bounds, n + 1, C.byref(nb)))
+        return [(int(bounds[k + 1]), int(bounds[k])) for k in range(nb.value)]
+
+    def allreduce_grads_overlapped(self, group=None):
+        """Call right behind loss_and_grads (which only ENQUEUES the step): bucket k's all-reduce waits for its event on a side stream and runs while
+        the main stream is still in the backward; the embedding-MLP / temb_proj gradients, final only at the end of the step, follow the whole step.
+        Same sums as allreduce_grads (a bucket is a slice of the same buffer)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        buckets = self.grad_buckets()
+        if not buckets:
+            return self.allreduce_grads(group)
+        main, side = torch.cuda.current_stream(self.device), self._comm_stream
+        works = []
+        with torch.cuda.stream(side):
+            for k, (lo, hi) in enumerate(buckets):
+                side.wait_event(self._gev[k])
+                works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            side.wait_stream(main)                                    # the rest is final when the whole step is
+            lo_all, hi_all = buckets[-1][0], buckets[0][1]
+            if lo_all > 0:
+                works.append(dist.all_reduce(self.grads[:lo_all], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if hi_all < self.grads.numel():
+                works.append(dist.all_reduce(self.grads[hi_all:], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            for w in works:
+                w.wait()
+        main.wait_stream(side)
+        self.grads.div_(dist.get_world_size(group))
+
     def optimizer_step(self):
         self.step += 1
         with torch.cuda.device(self.device):
@@ -160,7 +211,10 @@ class Trainer:
         t = torch.randint(low=0, high=self.num_timesteps, size=(n // 2 + 1,), device=self.device, generator=generator)
         t = torch.cat([t, self.num_timesteps - t - 1], dim=0)[:n]
         loss = self.loss_and_grads(x0, t, e)
-        self.allreduce_grads(group)
+        if getattr(self, "_gev", None):
+            self.allreduce_grads_overlapped(group)
+        else:
+            self.allreduce_grads(group)
         self.optimizer_step()
         return loss
 
