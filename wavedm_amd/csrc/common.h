@@ -246,6 +246,11 @@ int conv_dgrad(Ctx& c, int mode, const float* w_oihw, int cin, int cout, const T
 size_t conv_dgrad_packed_bytes(int cin, int cout, int k, int dtype);
 // forward layout [tap][rows_total][cin] AND dgrad layout [taps-1-tap][conv_rows_pad(cin)][cout padded] from one pass over the OIHW weights
 int k_pack_conv_both(const float* w_oihw, int cout, int cin, int k, void* dst_fwd, int rows_total, void* dst_dgrad, int dtype, hipStream_t s);
+// the same for a batch of layers of one kernel size in ceil(n / 12) launches (descriptors as kernel arguments); dstd may be nullptr (no dgrad layout wanted);
+// rows_d / kpad / gx / blk0 are filled in by the launcher
+struct PackDesc { const float* w; void* dstf; void* dstd; int cout, cin, rows_total, rows_d, kpad, gx, blk0; };
+struct PackBatch { static constexpr int MAX = 12; PackDesc d[MAX]; int n; };
+int k_pack_conv_both_batch(const PackDesc* descs, int n, int k, int dtype, hipStream_t s);
 // db / dtemb (optional): bias gradient and per-image column sums of dy (rows of length dtemb_ld), taken from the same pass that transposes dy
 int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy, int cout, float* dw, bool accumulate, float* db = nullptr, float* dtemb = nullptr,
                int dtemb_ld = 0);

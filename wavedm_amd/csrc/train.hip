@@ -488,11 +488,10 @@ template <typename T> static void l_sumpool2(hipStream_t s, const void* dy, int 
 }
 // one pass over OIHW: forward layout dstf[tap][rows_total][cin] (rows >= cout zero) and dgrad layout dstd[KK-1-tap][rows_d][kpad] (transposed)
 template <typename T, int KK>
-__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dstf, int rows_total, T* __restrict__ dstd,
-                                                        int rows_d, int kpad) {
+__device__ __forceinline__ void pack_both_tile(const float* __restrict__ w, int cout, int cin, T* __restrict__ dstf, int rows_total, T* __restrict__ dstd, int rows_d, int kpad,
+                                               int bx, int by, float (*sm)[32 * KK + 1]) {
     constexpr int ROW = 32 * KK;
-    __shared__ float sm[32][ROW + 1];
-    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int co0 = bx * 32, ci0 = by * 32;
     const int nci = min(32, cin - ci0);
     for (int r = threadIdx.x >> 5; r < 32; r += 8) {
         const int co = co0 + r;
@@ -506,8 +505,52 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
             // forward: row co0 + r, 32 consecutive input channels
             if (co0 + r < rows_total && ci0 + l < cin) TI<T>::st(dstf, ((long long)tp * rows_total + co0 + r) * cin + ci0 + l, sm[r][l * KK + tp]);
             // dgrad: row ci0 + r, 32 consecutive output channels, taps mirrored
-            if (ci0 + r < rows_d && co0 + l < kpad) TI<T>::st(dstd, ((long long)tp * rows_d + ci0 + r) * kpad + co0 + l, sm[l][r * KK + (KK - 1 - tp)]);
+            if (dstd != nullptr && ci0 + r < rows_d && co0 + l < kpad) TI<T>::st(dstd, ((long long)tp * rows_d + ci0 + r) * kpad + co0 + l, sm[l][r * KK + (KK - 1 - tp)]);
         }
+}
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dstf, int rows_total, T* __restrict__ dstd,
+                                                        int rows_d, int kpad) {
+    __shared__ float sm[32][32 * KK + 1];
+    pack_both_tile<T, KK>(w, cout, cin, dstf, rows_total, dstd, rows_d, kpad, (int)blockIdx.x, (int)blockIdx.y, sm);
+}
+// ... for a BATCH of layers in one launch (the training step packs all ~90 convs of the model after every optimiser step: one launch per layer was 4.6 % of
+// a 64-sample step, most of it launch latency).  The descriptors travel as kernel arguments; workgroup b belongs to the layer whose block range holds b.
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void pack_both_batch_kernel(const PackBatch pb) {
+    __shared__ float sm[32][32 * KK + 1];
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < pb.n; ++k) if ((int)blockIdx.x >= pb.d[k].blk0) j = k;
+    const PackDesc& d = pb.d[j];
+    const int local = (int)blockIdx.x - d.blk0;
+    pack_both_tile<T, KK>(d.w, d.cout, d.cin, (T*)d.dstf, d.rows_total, (T*)d.dstd, d.rows_d, d.kpad, local % d.gx, local / d.gx, sm);
+}
+int k_pack_conv_both_batch(const PackDesc* descs, int n, int k, int dtype, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += PackBatch::MAX) {
+        PackBatch pb;
+        pb.n = std::min(PackBatch::MAX, n - i0);
+        int blocks = 0;
+        for (int i = 0; i < pb.n; ++i) {
+            PackDesc d = descs[i0 + i];
+            d.rows_d = conv_rows_pad(d.cin);
+            d.kpad = (int)align_up((size_t)d.cout, kalign(dtype));
+            d.gx = (std::max(d.rows_total, d.kpad) + 31) / 32;
+            const int gy = (std::max(d.cin, d.rows_d) + 31) / 32;
+            d.blk0 = blocks;
+            blocks += d.gx * gy;
+            pb.d[i] = d;
+        }
+        if (dtype == WDM_BF16) {
+            if (k == 3) hipLaunchKernelGGL((pack_both_batch_kernel<__bf16, 9>), dim3(blocks), dim3(256), 0, s, pb);
+            else hipLaunchKernelGGL((pack_both_batch_kernel<__bf16, 1>), dim3(blocks), dim3(256), 0, s, pb);
+        } else {
+            if (k == 3) hipLaunchKernelGGL((pack_both_batch_kernel<float, 9>), dim3(blocks), dim3(256), 0, s, pb);
+            else hipLaunchKernelGGL((pack_both_batch_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, pb);
+        }
+    }
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
 }
 template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, int cout, int cin, int kk, void* dst, int rows, int kpad) {
     const dim3 grid((kpad + 31) / 32, (rows + 31) / 32);

@@ -237,7 +237,9 @@ struct wdm_trainer {
         params.push_back(p);
         return p.off;
     }
-    ConvP add_conv(const std::string& n, int cin, int cout, int k) { ConvP p; p.cin = cin; p.cout = cout; p.k = k; p.w = take(n + ".weight", {cout, cin, k, k}); p.b = take(n + ".bias", {cout}); return p; }
+    std::vector<ConvP> conv_list;                                   // every conv of the model, in construction order (packed together at the start of a step)
+    std::map<size_t, std::pair<void*, void*>> packed;              // weight offset -> (forward layout, dgrad layout) of this step
+    ConvP add_conv(const std::string& n, int cin, int cout, int k) { ConvP p; p.cin = cin; p.cout = cout; p.k = k; p.w = take(n + ".weight", {cout, cin, k, k}); p.b = take(n + ".bias", {cout}); conv_list.push_back(p); return p; }
     NormP add_norm(const std::string& n, int cc) { NormP p; p.c = cc; p.g = take(n + ".weight", {cc}); p.b = take(n + ".bias", {cc}); return p; }
     std::vector<std::pair<std::string, int>> temb_list;
     ResP add_res(const std::string& n, int cin, int cout) {
@@ -318,23 +320,16 @@ void wdm_trainer::build() {
 int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row, TT* res, TT** out) {
     Ctx& cx = *c;
     ConvW w; w.cin = p.cin; w.cout = p.cout; w.k = p.k; w.rows_pad = conv_rows_pad(p.cout); w.b = P + p.b;
-    void* pk = cx.ar->alloc(conv_packed_bytes(p.cin, p.cout, p.k, cx.dtype));
-    if (!pk) WDM_FAIL(WDM_ENOMEM, "training workspace too small (packed weights)");
-    // the backward's transposed weights are written by the same pass over the fp32 parameters and kept until the tape reaches this conv
-    void* wd = nullptr;
-    if (x0->needs_grad) {
-        wd = cx.ar->alloc(conv_dgrad_packed_bytes(p.cin, p.cout, p.k, cx.dtype));
-        if (!wd) WDM_FAIL(WDM_ENOMEM, "training workspace too small (dgrad weights)");
-        WDM_TRY(k_pack_conv_both(P + p.w, p.cout, p.cin, p.k, pk, w.rows_pad, wd, cx.dtype, cx.s));
-    } else {
-        WDM_TRY(k_pack_conv(P + p.w, p.cout, p.cin, p.k, pk, w.rows_pad, 0, 1, cx.dtype, cx.s));
-    }
+    // forward and transposed (dgrad) layouts of every conv were written at the start of the step (pack_all): one pass over the fp32 parameters
+    const auto it = packed.find(p.w);
+    if (it == packed.end()) WDM_FAIL(WDM_ESTATE, "training: conv weights were not packed for this step");
+    void* pk = it->second.first;
+    void* wd = x0->needs_grad ? it->second.second : nullptr;
     w.w = pk;
     TT* o = new_act();
     // want_stats: the conv's epilogue also leaves the GroupNorm partial statistics of its output (most conv outputs feed a GroupNorm)
     WDM_TRY(run_conv(cx, w, mode, x0->t, x1 ? &x1->t : nullptr, nullptr, nullptr, temb_row >= 0 ? temb_all + temb_row : nullptr, temb_rows, 1, res ? &res->t : nullptr, &o->t,
                      Y_NHWC, nullptr, true));
-    cx.ar->free(pk);
     *out = o;
     const ConvP pp = p;
     tape_rng.push_back({(long long)std::min(pp.w, pp.b), (long long)std::max(pp.w + (size_t)pp.cout * pp.cin * pp.k * pp.k, pp.b + (size_t)pp.cout)});
@@ -359,7 +354,6 @@ int wdm_trainer::op_conv(const ConvP& p, int mode, TT* x0, TT* x1, int temb_row,
                 cx.ar->free(tmp);
             }
         }
-        if (wd) cx.ar->free(wd);
         WDM_HIP(hipGetLastError());
         return WDM_OK;
     });
@@ -506,6 +500,30 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     hipLaunchKernelGGL(silu_f32_kernel, dim3(nbu((long long)B * temb_ch, 256)), dim3(256), 0, cc.s, t1, s1, (long long)B * temb_ch);
     WDM_TRY(k_linear(s1, B, temb_ch, P + tw, P + tb, temb_rows, temb_all, 0, cc.s));
     WDM_HIP(hipMemsetAsync(d_temb_all, 0, (size_t)B * temb_rows * 4, cc.s));
+    // ---- forward and dgrad weight layouts of all convs (the parameters changed in the last optimiser step): a dozen launches for ~90 layers
+    char* pack_region = nullptr;
+    {
+        size_t bytes = 0;
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        for (const ConvP& q : conv_list) bytes += up(conv_packed_bytes(q.cin, q.cout, q.k, cc.dtype)) + up(conv_dgrad_packed_bytes(q.cin, q.cout, q.k, cc.dtype));
+        pack_region = (char*)cc.ar->alloc(bytes);
+        if (!pack_region) WDM_FAIL(WDM_ENOMEM, "training workspace too small (packed weights)");
+        packed.clear();
+        std::vector<PackDesc> d3, d1;
+        size_t off = 0;
+        for (const ConvP& q : conv_list) {
+            PackDesc d{};
+            d.w = P + q.w; d.cout = q.cout; d.cin = q.cin; d.rows_total = conv_rows_pad(q.cout);
+            d.dstf = pack_region + off; off += up(conv_packed_bytes(q.cin, q.cout, q.k, cc.dtype));
+            d.dstd = pack_region + off; off += up(conv_dgrad_packed_bytes(q.cin, q.cout, q.k, cc.dtype));
+            packed[q.w] = {d.dstf, d.dstd};
+            (q.k == 3 ? d3 : d1).push_back(d);
+        }
+        if (!cc.dry) {
+            WDM_TRY(k_pack_conv_both_batch(d3.data(), (int)d3.size(), 3, cc.dtype, cc.s));
+            WDM_TRY(k_pack_conv_both_batch(d1.data(), (int)d1.size(), 1, cc.dtype, cc.s));
+        }
+    }
     // ---- network input: [x_cond | x_t | x_other] with x_t = sqrt(a) x_tar + sqrt(1-a) e
     TT* xin = new_act();
     xin->needs_grad = false;
@@ -547,13 +565,9 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
     if (!outf) WDM_FAIL(WDM_ENOMEM, "training workspace too small (output)");
     {
         ConvW w; w.cin = conv_out.cin; w.cout = pc; w.k = 3; w.rows_pad = conv_rows_pad(pc); w.b = P + conv_out.b;
-        void* pk = cc.ar->alloc(conv_packed_bytes(conv_out.cin, pc, 3, cc.dtype));
-        if (!pk) WDM_FAIL(WDM_ENOMEM, "training workspace too small (packed weights)");
-        WDM_TRY(k_pack_conv(P + conv_out.w, pc, conv_out.cin, 3, pk, w.rows_pad, 0, 1, cc.dtype, cc.s));
-        w.w = pk;
+        w.w = packed.at(conv_out.w).first;
         Tens dummy;
         WDM_TRY(run_conv(cc, w, MODE_S1, an->t, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &dummy, Y_NHWC_F32, outf));
-        cc.ar->free(pk);
     }
     // ---- loss and its gradient
     void* dout = cc.ar->alloc((size_t)B * R * R * pc * es);
@@ -570,7 +584,7 @@ int wdm_trainer::step(Ctx& cc, const float* x0, const float* t, const float* sa,
         WDM_TRY(colsum(cc, dy, G + conv_out.b, false, false));
         WDM_TRY(conv_wgrad(cc, MODE_S1, an->t, nullptr, dy, pc, G + conv_out.w, false));
         bool f; WDM_TRY(grad_buf(an, &f));
-        WDM_TRY(conv_dgrad(cc, MODE_S1, P + conv_out.w, conv_out.cin, pc, dy, R, R, an->g, false));
+        WDM_TRY(conv_dgrad(cc, MODE_S1, P + conv_out.w, conv_out.cin, pc, dy, R, R, an->g, false, packed.at(conv_out.w).second));
     }
     // The tape runs in reverse; the parameters sit in the flat buffers in forward order, so the gradient buffer fills from its END.  With events set
     // (wdm_trainer_set_grad_events) the range finished so far is cut into buckets and an event is recorded behind each: the caller's all-reduce of a bucket
