@@ -560,6 +560,36 @@ template <typename T> static void l_pack_dgrad(hipStream_t s, const float* w, in
 template <typename T> static void l_pad_channels(hipStream_t s, const void* x, int C, int Cp, void* y, long long total) {
     hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(nblk(total, 256)), dim3(256), 0, s, (const T*)x, C, Cp, (T*)y, total);
 }
+// per-image column sums in ONE launch: out[g][c] = sum over the rows of image g of x[g][row][c].  grid (ceil(C / 64), images), 256 threads = (64 / VEC channel
+// vectors) x (row lanes); a row lane adds its rows in ascending order, the lanes are joined in ascending order.  (colsum_part + colsum_final: two launches.)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_img_kernel(const T* __restrict__ x, int xs, int C, int rows, float* __restrict__ out, int out_ld, int accumulate) {
+    constexpr int VEC = TI<T>::VEC, CV = 64 / VEC, RL = 256 / CV;
+    __shared__ float red[RL][65];
+    const int g = blockIdx.y, cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+    const int c = blockIdx.x * 64 + cv * VEC;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (c < C) {
+        const T* p = x + (long long)g * rows * xs + c;
+        for (int r = rl; r < rows; r += RL) {
+            float f[VEC];
+            TI<T>::unpack(*(const uint4*)(p + (long long)r * xs), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[rl][cv * VEC + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < C) {
+        float t = 0.f;
+        for (int k = 0; k < RL; ++k) t += red[k][threadIdx.x];
+        const long long o = (long long)g * out_ld + blockIdx.x * 64 + threadIdx.x;
+        out[o] = accumulate ? out[o] + t : t;
+    }
+}
 // needs a scratch buffer of groups * nchunks * C floats
 static inline int colsum_chunks(long long rows_per_group) { long long n = (rows_per_group + 255) / 256; return (int)(n < 1 ? 1 : (n > 256 ? 256 : n)); }
 template <typename T> static void l_colsum(hipStream_t s, const void* x, int xs, int C, long long rows_per_group, int groups, float* out, int acc, int out_ld,
@@ -844,7 +874,14 @@ int colsum(Ctx& c, const Tens& dy, float* out, bool per_image, bool accumulate, 
     float* scratch = (float*)c.ar->alloc((size_t)groups * colsum_chunks(rows) * dy.C * sizeof(float));
     if (!scratch) WDM_FAIL(WDM_ENOMEM, "workspace too small (column sums)");
     if (!c.dry) {
-        BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, groups, out, accumulate ? 1 : 0, out_ld, scratch);
+        const int vec = c.dtype == WDM_BF16 ? 8 : 4;
+        if (per_image && dy.C % vec == 0 && dy.xs % vec == 0 && rows <= (1 << 20)) {        // one launch per tensor; a thread walks rows / 32 (16) rows
+            const dim3 grid((dy.C + 63) / 64, groups);
+            if (c.dtype == WDM_BF16) hipLaunchKernelGGL(colsum_img_kernel<__bf16>, grid, dim3(256), 0, c.s, (const __bf16*)dy.p, dy.xs, dy.C, (int)rows, out, out_ld ? out_ld : dy.C, accumulate ? 1 : 0);
+            else hipLaunchKernelGGL(colsum_img_kernel<float>, grid, dim3(256), 0, c.s, (const float*)dy.p, dy.xs, dy.C, (int)rows, out, out_ld ? out_ld : dy.C, accumulate ? 1 : 0);
+        } else {
+            BY_DTYPE(c.dtype, l_colsum, c.s, dy.p, dy.xs, dy.C, rows, groups, out, accumulate ? 1 : 0, out_ld, scratch);
+        }
         WDM_HIP(hipGetLastError());
     }
     c.ar->free(scratch);
