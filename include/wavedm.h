@@ -17,7 +17,7 @@
  *   - one wdm_handle per device, one wdm_unet per model; a handle/unet is not thread-safe,
  *     distinct handles are independent;
  *   - "NCHW f32" tensors are the reference's layout at the boundary; inside the UNet
- *     activations are NHWC (channels-last) in the model dtype (WDM_BF16 or WDM_F32).
+ *     activations are NHWC (channels-last) in the model dtype (WDM_BF16 / WDM_F16: 2 bytes, WDM_F32 / WDM_F32X3: 4).
  */
 #ifndef WAVEDM_H
 #define WAVEDM_H
@@ -42,8 +42,12 @@ enum {
 
 /* WDM_F32X3: fp32 tensors exactly as WDM_F32 (same buffers, same elementwise kernels); only the contractions differ -- each product is three
  * bf16 MFMAs on operands split hi + lo in registers (~1e-5 end to end, several times the rate of the exact-fp32 MFMA chain).  UNet / block /
- * conv entry points take it; the HFRM and the trainer take WDM_F32 or WDM_BF16. */
-enum { WDM_F32 = 0, WDM_BF16 = 1, WDM_F32X3 = 2 };
+ * conv entry points take it; the HFRM and the trainer take WDM_F32 or WDM_BF16.
+ * WDM_F16: the bf16 path on IEEE half operands -- fp16 tensors and packed weights, v_mfma_f32_16x16x32_f16 (the bf16 MFMA's rate), fp32 accumulators,
+ * GroupNorm statistics, softmax and DDIM state exactly as in WDM_BF16.  Three more mantissa bits than bf16 (unit round-off 2^-11): the mode meant to
+ * meet the 1e-3 parity bound at the bf16 mode's speed.  The price is range (|x| <= 65504): wdm_unet_load_param fails with WDM_EINVAL on a weight outside
+ * it.  UNet / block / conv / layout entry points take it; the HFRM and the trainer do not. */
+enum { WDM_F32 = 0, WDM_BF16 = 1, WDM_F32X3 = 2, WDM_F16 = 3 };
 
 typedef struct wdm_handle wdm_handle;
 typedef struct wdm_unet wdm_unet;
@@ -125,7 +129,7 @@ typedef struct wdm_unet_config {
     int out_ch;              /* 3 (12 / 48 with data.use_window / data.wavelet_in_unet) */
     int resolution;          /* data.image_size */
     int resamp_with_conv;    /* must be 1 */
-    int dtype;               /* WDM_BF16 (throughput), WDM_F32 (exact parity mode) or WDM_F32X3 (fast parity mode) */
+    int dtype;               /* WDM_BF16 (throughput), WDM_F16 (throughput, fp16 operands), WDM_F32 (exact parity mode) or WDM_F32X3 (fast parity mode) */
 } wdm_unet_config;
 
 int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out);

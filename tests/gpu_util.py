@@ -6,10 +6,11 @@ import torch
 from wavedm_amd import _lib
 from wavedm_amd import procedural as P
 
-DT = {"f32": _lib.WDM_F32, "bf16": _lib.WDM_BF16, "f32x3": _lib.WDM_F32X3}
+DT = {"f32": _lib.WDM_F32, "bf16": _lib.WDM_BF16, "f32x3": _lib.WDM_F32X3, "f16": _lib.WDM_F16}
 # tolerances (max-norm relative): f32 is the parity mode of BASELINE.json's north_star (1e-3);
 # bf16 is the throughput mode -- its deviation is bounded here (<= 2x the measured worst case) so regressions show, it is not a parity claim.
-TOL = {"f32": 1e-3, "f32x3": 1e-3, "bf16": 1e-2}
+# f16 (fp16 operands, fp32 accumulation) is held to the parity bound itself.
+TOL = {"f32": 1e-3, "f32x3": 1e-3, "f16": 1e-3, "bf16": 1e-2}
 
 
 def dev():

@@ -58,7 +58,7 @@ def test_dwt_golden_and_properties(gu, O, golden):
 
 
 # ----------------------------------------------------------------------------------------- convs
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 @pytest.mark.parametrize("mode,cin,cout,B,H", [
     (0, 64, 128, 2, 16), (0, 96, 128, 1, 32), (0, 128, 3, 2, 16), (0, 64, 64, 3, 8), (0, 128, 3, 1, 8),
     (1, 64, 64, 2, 16), (1, 64, 64, 2, 32), (2, 64, 64, 2, 8), (2, 128, 128, 1, 16), (2, 96, 160, 3, 16), (2, 256, 256, 2, 32), (2, 128, 128, 5, 8), (2, 96, 136, 4, 8),
@@ -127,7 +127,7 @@ def _attn_shapes(c):
     return s
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 @pytest.mark.parametrize("name,cin,cout,xs,sx,ts,st,split", [
     ("rb_a", 64, 128, (2, 64, 16, 16), 10, (2, 512), 11, 0),
     ("rb_b", 128, 128, (2, 128, 8, 8), 12, (1, 512), 13, 0),
@@ -144,7 +144,7 @@ def test_resblock_golden(gu, O, golden, dtype, name, cin, cout, xs, sx, ts, st, 
     assert rel_linf(got, O.resnet_block(sd, name, x, temb)) <= gu.TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 def test_attn_golden(gu, O, golden, dtype):
     b = golden("blocks.npz")
     x = gu.seeded((1, 512, 16, 16), 20)

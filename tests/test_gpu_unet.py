@@ -13,7 +13,7 @@ torch.set_grad_enabled(False)
 
 # f32 = the parity mode (north_star: 1e-3 max-norm-relative).  bf16 = the throughput mode: bounded at <= 2x what this suite measures on
 # the MI355X (printed by every test; 3.5e-3 ... 4.6e-3 on the full model, worst case 6.0e-3 on the reduced one), so a regression shows.
-TOL = {"f32": 1e-3, "f32x3": 1e-3, "bf16": 1e-2}
+TOL = {"f32": 1e-3, "f32x3": 1e-3, "f16": 1e-3, "bf16": 1e-2}
 
 
 def seeded(shape, seed):
@@ -40,14 +40,15 @@ def make_diffusion(cfg, dtype, S, generator=lambda x: x):
     return d, args
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 def test_reduced_unet_forward(golden, dtype):
     from wavedm_amd import procedural as P
     r = golden("reduced.npz")
     net = build(P.reduced_config(), dtype)
     x96 = seeded((2, 96, 16, 16), 40).cuda()
-    # the reduced model (32-channel levels, 8-channel GroupNorm groups) is the noisiest case in bf16: 1.1e-2 measured on one forward
-    tol = TOL[dtype] if dtype != "bf16" else 2e-2
+    # the reduced model (32-channel levels, 8-channel GroupNorm groups; not a BASELINE config) is the noisiest case for 16-bit operands: 1.1e-2 measured on one
+    # forward in bf16, 1.35e-3 in f16 (the eightfold smaller round-off); the BASELINE configs below hold f16 to 1e-3
+    tol = {"bf16": 2e-2, "f16": 2.5e-3}.get(dtype, TOL[dtype])
     e1 = rel_linf(net(x96, torch.tensor([500.0])).cpu(), r["fwd_t500"])
     e2 = rel_linf(net(x96, torch.tensor([990.0, 10.0])).cpu(), r["fwd_t_per_image"])
     print(f"reduced forward {dtype}: rel_linf {e1:.3e} {e2:.3e}")
@@ -115,7 +116,7 @@ def test_stitched_restore(golden, dtype):
         assert e0 <= TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16"])
 def test_full_unet_forward_f32(golden, dtype):
     """The 156 M-parameter UNet against the reference's own output, in both parity modes (exact fp32 MFMA; fp32 tensors with every
     product as three bf16 MFMAs on hi/lo-split operands)."""
@@ -134,7 +135,7 @@ def test_full_unet_forward_f32(golden, dtype):
     assert e <= 1e-3
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 def test_config0_sampler(golden, dtype):
     """BASELINE.json configs[0]: 4x64x64, 10 DDIM steps, full-width model, vs the reference's own output."""
     from wavedm_amd import procedural as P
@@ -161,7 +162,7 @@ def test_c1_length_against_the_oracle():
     xs_cpu, x0_cpu = O.ddim_batch(sd, cfg, x_T, xc, xc[:, 3:].contiguous(), 100, chunk=4)
     want_xs, want_x0 = xs_cpu[-1], x0_cpu[-5]
     res = {}
-    for dtype in ("f32", "f32x3", "bf16"):
+    for dtype in ("f32", "f32x3", "f16", "bf16"):
         d, _ = make_diffusion(cfg, dtype, 100)
         out, xs_last, x0m5 = d.restore_batch(rainy.cuda(), x_T.cuda())
         res[dtype] = (xs_last.cpu(), x0m5.cpu(), out.cpu())
@@ -172,7 +173,7 @@ def test_c1_length_against_the_oracle():
         print(f"C1 length (4 x 100 steps) {k} vs the oracle: rel_linf xs[-1] {e1:.3e}  x0[-5] {e2:.3e}")
     print(f"C1 length bf16 vs f32 (HIP): {rel_linf(res['bf16'][0], res['f32'][0]):.3e}")
     assert torch.isfinite(res["bf16"][2]).all()
-    assert max(err["f32"]) <= 1e-3 and max(err["f32x3"]) <= 1e-3           # north_star's tolerance over the full trajectory
+    assert max(err["f32"]) <= 1e-3 and max(err["f32x3"]) <= 1e-3 and max(err["f16"]) <= 1e-3           # north_star's tolerance over the full trajectory
     assert max(err["bf16"]) <= 6e-3                                         # 2x the measured 2.7e-3 ... 3.0e-3
 
 
@@ -201,7 +202,7 @@ def test_config2_r128_forward():
     x = seeded((2, 96, 128, 128), 7)
     t = torch.tensor([470.0])
     want = O.unet_forward(sd, cfg, x, t)
-    for dtype in ("f32", "f32x3", "bf16"):
+    for dtype in ("f32", "f32x3", "f16", "bf16"):
         import wavedm_amd
         net = wavedm_amd.DiffusionUNet(cfg, dtype=dtype)
         net.load_state_dict(sd, strict=True)
@@ -225,7 +226,7 @@ def test_config2_r128_sampler():
     assert x_T.shape == (2, 3, 128, 128)
     xc = O.dwt_fwd(2 * rainy - 1)
     oxs, ox0 = O.ddim_batch(sd, cfg, x_T, xc, xc[:, 3:].contiguous(), 10, chunk=2)
-    for dtype in ("f32", "f32x3", "bf16"):
+    for dtype in ("f32", "f32x3", "f16", "bf16"):
         d, _ = make_diffusion(P.raindrop_wavelet_config(image_size=128), dtype, 10)
         out, xs_last, x0m5 = d.restore_batch(rainy.cuda(), x_T.cuda())
         e1, e2 = rel_linf(xs_last.cpu(), oxs[-1]), rel_linf(x0m5.cpu(), ox0[-5])
@@ -266,7 +267,7 @@ def test_config2_b256_properties_bf16():
         del out, xs_last, x0
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16", "bf16"])
 def test_config4_fullres_stitch(dtype):
     """BASELINE.json configs[4] geometry: one 480x720 image -> 120x180 wavelet domain -> 45 overlapping 64x64 patches
     (r = 16) through the full-width UNet, DiffusiveRestoration.restore end to end, 5 DDIM steps, vs the CPU oracle."""

@@ -10,9 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVEDM_LIB") or os.path.join(_HERE, "csrc", "libwavedm_hip.so")     # WAVEDM_LIB: another build of the same ABI (A/B runs)
 
-WDM_F32, WDM_BF16, WDM_F32X3 = 0, 1, 2
+WDM_F32, WDM_BF16, WDM_F32X3, WDM_F16 = 0, 1, 2, 3
 WDM_OK, WDM_EINVAL, WDM_ENOMEM, WDM_EHIP, WDM_ESTATE, WDM_ENOTFOUND = 0, -1, -2, -3, -4, -5
-DTYPES = {"f32": WDM_F32, "fp32": WDM_F32, "float32": WDM_F32, "bf16": WDM_BF16, "bfloat16": WDM_BF16, "f32x3": WDM_F32X3}
+DTYPES = {"f32": WDM_F32, "fp32": WDM_F32, "float32": WDM_F32, "bf16": WDM_BF16, "bfloat16": WDM_BF16, "f32x3": WDM_F32X3, "f16": WDM_F16, "fp16": WDM_F16, "float16": WDM_F16, "half": WDM_F16}
 
 _lib = None
 _handles = {}

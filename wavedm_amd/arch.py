@@ -31,7 +31,7 @@ class HFRM(nn.Module):
         self.in_channel, self.dim = int(in_channel), int(dim)
         self.padder_size = 2 ** len(enc_blk_nums)
         self._dtype_code = resolve_dtype(None, dtype)
-        if self._dtype_code == _lib.WDM_F32X3:               # the HFRM has two modes; the fast parity mode of the UNet maps to its exact one
+        if self._dtype_code in (_lib.WDM_F32X3, _lib.WDM_F16):      # the HFRM has two modes; the parity modes of the UNet (f32x3, f16) map to its exact one
             self._dtype_code = _lib.WDM_F32
         cfg = _lib.HFRMConfig()
         cfg.in_channel, cfg.dim, cfg.mid_blk_num = self.in_channel, self.dim, int(mid_blk_num)

@@ -1,5 +1,6 @@
 // Launcher of the fused attention core (attn_fused_kernel.h).
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 #include "attn_fused_kernel.h"
@@ -8,11 +9,12 @@ namespace wdm {
 
 bool attn_fused_eligible(int dtype, int N, int C) {
     // one phase-2 pass over <= 512 channels, two over the halves above that (the halves must be whole wave fragments: multiples of 128)
-    return env_cfg().attn_fused && dtype == WDM_BF16 && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C &&
+    return env_cfg().attn_fused && is_h16(dtype) && N == AttnFusedCfg::N && C % 128 == 0 && C >= 128 && C <= AttnFusedCfg::MAX_C &&
            (C <= AttnFusedCfg::MAX_CP || (C / 2) % 128 == 0);
 }
 
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias, const ConvArgs* proj) {
+template <typename T>
+static int launch_attn_fused_t(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias, const ConvArgs* proj) {
     using Cf = AttnFusedCfg;
     if (!qk || !vT || (!o && !proj) || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
     if (proj && (C > 512 || proj->Cout != C || proj->Cin != C || proj->Hout != 16 || proj->Wout != 16 || proj->B != B || !proj->w || proj->w_bytes == 0 || proj->y_mode != Y_NHWC ||
@@ -28,25 +30,30 @@ int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hip
     int dev = 0;
     WDM_HIP(hipGetDevice(&dev));
     if (!(devs.load() & (1u << (dev & 31)))) {
-        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
-        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
+        WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<true, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         devs.fetch_or(1u << (dev & 31));
     }
     const bool prof = prof_enabled();
     if (prof) {
         char name[96];
-        snprintf(name, sizeof(name), "attn_fused_n256_bf16|16x16 C=%d%s", C, proj ? " +proj" : "");
+        snprintf(name, sizeof(name), "attn_fused_n256_%s|16x16 C=%d%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", C, proj ? " +proj" : "");
         prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
                    (double)B * Cf::N * C * 2.0 * (proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0));
     }
     ConvArgs pe{};
     if (proj) pe = *proj;
     pe.fin_total = AttnFusedCfg::N / AttnFusedCfg::QB;          // gn_arrive.h: the image's query blocks
-    if (proj) hipLaunchKernelGGL(attn_fused_kernel<true>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
-    else hipLaunchKernelGGL(attn_fused_kernel<false>, dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
+    if (proj) hipLaunchKernelGGL((attn_fused_kernel<true, T>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
+    else hipLaunchKernelGGL((attn_fused_kernel<false, T>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
     if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
+}
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias, const ConvArgs* proj, int dtype) {
+    if (dtype == WDM_F16) return launch_attn_fused_t<f16_t>(qk, vT, o, B, C, s, vbias, proj);
+    if (dtype == WDM_BF16) return launch_attn_fused_t<__bf16>(qk, vT, o, B, C, s, vbias, proj);
+    WDM_FAIL(WDM_EINVAL, "attn(fused): 16-bit modes only");
 }
 
 }  // namespace wdm

@@ -53,10 +53,10 @@ struct AttnFusedCfg {
     static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <bool PROJ>
+template <bool PROJ, typename T_ = __bf16>
 __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a, const ConvArgs pe) {
     using C = AttnFusedCfg;
-    using T = __bf16;
+    using T = T_;
     constexpr int N = C::N, QB = C::QB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;

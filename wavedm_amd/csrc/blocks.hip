@@ -113,12 +113,12 @@ const EnvCfg& env_cfg() {
 }
 
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout) {
-    return env_cfg().up4 && (dtype == WDM_BF16 || dtype == WDM_F32X3) && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
+    return env_cfg().up4 && (is_h16(dtype) || dtype == WDM_F32X3) && ((H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) && cin % 32 == 0 && cout % 8 == 0 && cout >= 128;
 }
 
 int launch_conv(const ConvArgs& a0, int mode, int dtype, hipStream_t s) {
     const ConvArgs& a = a0;
-    return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
+    return dtype == WDM_BF16 ? launch_conv_bf16(a, mode, s) : dtype == WDM_F16 ? launch_conv_f16(a, mode, s) : dtype == WDM_F32X3 ? launch_conv_f32x3(a, mode, s) : launch_conv_f32(a, mode, s);
 }
 // ---- one fused convolution ---------------------------------------------------------------------
 // out: allocated here (NHWC model dtype) unless y_ext is given (then y_mode says how y_ext is laid out)
@@ -184,7 +184,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
             a.yn = out->nrm; a.on_gamma = on->g; a.on_beta = on->b; a.on_eps = 1e-6f; a.on_silu = on_silu;
         }
         // group-level partials ride behind the per-channel ones where a consumer can finalise from them (gn_inline.h): group widths 4 / 8 / 16
-        const bool want_gst = c.dtype == WDM_BF16 && env_cfg().gn_inline && gn_inline_shape_ok(w.cout, nslab);
+        const bool want_gst = is_h16(c.dtype) && env_cfg().gn_inline && gn_inline_shape_ok(w.cout, nslab);
         const size_t sb = gn_stats_bytes(c.B, nslab, w.cout);
         out->stats = (float*)c.ar->alloc(sb + (want_gst ? (size_t)c.B * nslab * 96 * sizeof(float) : 0));
         if (!out->stats) WDM_FAIL(WDM_ENOMEM, "workspace too small (GroupNorm statistics)");
@@ -192,7 +192,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
         if (want_gst) { out->gst = (float*)((char*)out->stats + sb); a.gst = out->gst; }
         // the consumer's GroupNorm finalised by this launch's last workgroups (gn_arrive.h) instead of a gn_finalize launch
         const int Cf = w.cout + ((fin && fin->other) ? fin->other->C : 0);
-        if (fin && fin_ok && env_cfg().gn_inline >= 2 && c.fin_cnt && c.fin_used < c.fin_cap && c.dtype == WDM_BF16 && fin->n->c == Cf && (!fin->other || fin->other->stats) &&
+        if (fin && fin_ok && env_cfg().gn_inline >= 2 && c.fin_cnt && c.fin_used < c.fin_cap && is_h16(c.dtype) && fin->n->c == Cf && (!fin->other || fin->other->stats) &&
             (double)c.B * nslab * w.cout * 16.0 < 2147483000.0) {
             WDM_TRY(alloc_f32(c, (size_t)c.B * Cf, &out->fin_scale));
             WDM_TRY(alloc_f32(c, (size_t)c.B * Cf, &out->fin_shift));
@@ -215,7 +215,7 @@ static bool has_fin(const Tens& x0, const Tens* x1, const NormW& nw, int silu) {
     return x0.fin_scale != nullptr && x0.fin_for == nw.g && x0.fin_silu == silu && x0.fin_other == (x1 ? x1->p : nullptr);
 }
 bool wants_fin(const Ctx& c, int Cin, int H, int W, bool single) {
-    if (env_cfg().gn_inline < 2 || !env_cfg().conv_dma || c.dtype != WDM_BF16 || !c.fin_cnt || H * W <= GN_PASS_MAX_HW || H % 16 || W % 16) return false;
+    if (env_cfg().gn_inline < 2 || !env_cfg().conv_dma || !is_h16(c.dtype) || !c.fin_cnt || H * W <= GN_PASS_MAX_HW || H % 16 || W % 16) return false;
     const bool inl = single && env_cfg().gn_inline && gn_inline_shape_ok(Cin, (H / 16) * (W / 16) * 4);      // the consumer finalises in its own prologue (gn_inline.h)
     return !inl;
 }
@@ -309,7 +309,7 @@ static int materialize_gn_silu(Ctx& c, const NormW& nw, const Tens& x0, const Te
 // persistent kernel, which walks an image's tiles back to back and keeps the table under the packed epilogue: 609.3 / 612.9 -> 609.7 / 614.1 img/s at 20 steps, null --
 // the table set-up inside the kernel costs what the gn_finalize launch did.  Those layers keep gn_finalize.)
 static bool gn_inline_ok(const Ctx& c, const Tens& x0, const Tens* x1, int cout) {
-    return env_cfg().gn_inline && env_cfg().conv_dma && c.dtype == WDM_BF16 && !x1 && x0.gst != nullptr && gn_inline_shape_ok(x0.C, x0.nslab) && x0.H % 16 == 0 &&
+    return env_cfg().gn_inline && env_cfg().conv_dma && is_h16(c.dtype) && !x1 && x0.gst != nullptr && gn_inline_shape_ok(x0.C, x0.nslab) && x0.H % 16 == 0 &&
            x0.W % 16 == 0 && cout >= 128;
 }
 
@@ -348,8 +348,8 @@ int run_resblock(Ctx& c, const ResW& w, const Tens& x0, const Tens* x1, Tens* ou
     // the 1x1 shortcut either runs as its own GEMM (result added in conv2's epilogue) or, where conv2 runs on the LDS-DMA kernel,
     // as a second K phase of conv2 itself: x_shortcut + h is then one fp32 accumulator and the shortcut tensor never exists
     // (8 x 8 maps: conv2 has no prologue there and runs on conv_dma8_kernel.h; WDM_CONV_DMA=0 takes the LDS-DMA kernels, hence the fusion, away)
-    const bool fuse_nin = w.has_nin && env_cfg().conv_dma && (!pass || (x0.H == 8 && x0.W == 8 && c.dtype == WDM_BF16)) &&
-                          (c.dtype == WDM_BF16 || (c.dtype == WDM_F32X3 && x0.H % 16 == 0 && x0.W % 16 == 0)) &&
+    const bool fuse_nin = w.has_nin && env_cfg().conv_dma && (!pass || (x0.H == 8 && x0.W == 8 && is_h16(c.dtype))) &&
+                          (is_h16(c.dtype) || (c.dtype == WDM_F32X3 && x0.H % 16 == 0 && x0.W % 16 == 0)) &&
                           conv_can_fuse_shortcut(x0.H, x0.W, w.cout, w.cout, x0.C, x1 ? x1->C : 0);
     const Tens* res = &x0;
     if (w.has_nin && !fuse_nin) {
@@ -425,7 +425,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
         odummy.p = qk.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
         WDM_TRY(run_conv(c, w.proj, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
                          next_fin));
-        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, nullptr, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, &a_proj));
+        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, nullptr, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, &a_proj, c.dtype));
         c.ar->free(vT);
         free_tens(c, qk);
         return WDM_OK;
@@ -433,7 +433,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
     if (fused) {
         // scores, softmax and P.V in one kernel: S and P never leave the CU (attn_fused_kernel.h)
         WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
-        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr));
+        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, nullptr, c.dtype));
         c.ar->free(vT);
     } else {
     float* S = nullptr;

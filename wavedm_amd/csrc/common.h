@@ -29,7 +29,15 @@ void set_error(const char* fmt, ...);
         if (rc__ != WDM_OK) return rc__; \
     } while (0)
 
-inline size_t dsize(int dtype) { return dtype == WDM_BF16 ? 2 : 4; }
+inline bool is_h16(int dtype) { return dtype == WDM_BF16 || dtype == WDM_F16; }      // the 16-bit modes: same kernels, layouts and eligibility rules
+inline size_t dsize(int dtype) { return is_h16(dtype) ? 2 : 4; }
+inline bool dtype_valid(int dtype) { return dtype == WDM_F32 || dtype == WDM_BF16 || dtype == WDM_F32X3 || dtype == WDM_F16; }
+// launch a kernel template on the 16-bit element type of `dtype` (H16 = __bf16 or f16_t inside the statement)
+#define WDM_H16_SWITCH(dtype, ...)                                          \
+    do {                                                                    \
+        if ((dtype) == WDM_F16) { using H16 = wdm::f16_t; __VA_ARGS__; }      \
+        else { using H16 = __bf16; __VA_ARGS__; }                                 \
+    } while (0)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- deterministic first-fit arena over a caller-provided buffer -----------------------------
@@ -172,12 +180,14 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
 // 64 B each, and in the plain matrix a 1 KB DMA piece touches 16 half cache lines (27.6 cycles of the CU's vector-memory path, tools/dma_ubench.hip);
 // here it is one contiguous run of 8 whole lines (15 cycles)
 // (f32x3 mode: the same slot holds the pre-split copy of conv_dmax3_kernel.h, plain [tap][row][cin] order, 16-channel groups as [hi | hi | lo | lo])
-inline bool conv_sm_eligible(int dtype, int k, int cin) { return (dtype == WDM_BF16 && k == 3 && cin % 32 == 0) || (dtype == WDM_F32X3 && k == 3 && cin % 16 == 0); }
+inline bool conv_sm_eligible(int dtype, int k, int cin) { return (is_h16(dtype) && k == 3 && cin % 32 == 0) || (dtype == WDM_F32X3 && k == 3 && cin % 16 == 0); }
 int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
 int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout);      // sub-pixel Upsample kernel applies to this low-resolution map
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
 int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s);
+// *flag_dev (device int, zeroed by the caller) = 1 if any |x[i]| > limit or x[i] is not finite: the fp16 range check of the weight loader
+int k_flag_out_of_range(const float* x, long long n, float limit, int* flag_dev, hipStream_t s);
 
 // ---- live kernel timing (prof.hip): HIP events on the launch stream around every conv launch ------
 int concurrent_streams();      // prof.hip: wdm_set_concurrent_streams
@@ -197,7 +207,7 @@ bool attn_fused_eligible(int dtype, int N, int C);
 // vbias != nullptr: vT was computed without the v bias, which is added to the output instead
 // proj != nullptr (C <= 512): proj_out fused in as a third phase; *proj = the 1x1 conv's arguments as run_conv builds them (weights, bias, residual, output,
 // statistics); o is then unused
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr, const ConvArgs* proj = nullptr);
+int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr, const ConvArgs* proj = nullptr, int dtype = WDM_BF16);
 
 // ---- experiment switches (environment), read ONCE -- at first use or when wdm_env_refresh() is called (tests and A/B harnesses that change the
 // environment inside a running process call it); no launch path calls getenv.  Defaults are the measured best.

@@ -61,11 +61,11 @@ struct ConvDma256Cfg {
 // PACKED: the launcher's conv_epilogue_can_pack(a) (one epilogue form per kernel: with both, the 128 accumulator registers leave the allocator no room)
 // SC = false: no shortcut phase in the binary (the 512 x 128 tile with the bf16-tile epilogue AND the shortcut phase leaves the allocator 60 ... 90 spilled
 // accumulator registers -- 47 MB of scratch traffic per round of workgroups, +50 us on a 64 x 64 launch; launches with a fused shortcut stay on 256 x 128)
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_, bool PACKED = false, bool SC = true>
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int TH_, bool PACKED = false, bool SC = true, typename T_ = __bf16>
 __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     using C = ConvDma256Cfg<WAVES_M_, WAVES_N_, WM_, WN_, TH_>;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
-    using T = __bf16;
+    using T = T_;
     constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 

@@ -48,10 +48,10 @@ struct ConvDma8Cfg {
     static_assert(WAVES_M * WM * 16 == NI * TH * TW && WAVES_N * WN * 16 == BN && A_CPW * NWAVES * 16 == A_ROWS && 3 * BN <= B_SUB / 64, "tile");
 };
 
-template <int BN_, int NI_ = 2>
+template <int BN_, int NI_ = 2, typename T_ = __bf16>
 __global__ __launch_bounds__((ConvDma8Cfg<BN_, NI_>::NTHREADS), 2) void conv_dma8_kernel(const ConvArgs a) {
     using C = ConvDma8Cfg<BN_, NI_>;
-    using T = __bf16;
+    using T = T_;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, NI = C::NI, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 

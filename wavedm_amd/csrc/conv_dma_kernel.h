@@ -60,11 +60,11 @@ struct ConvDmaCfg {
 
 // PACKED: the launcher's conv_epilogue_can_pack(a) (one epilogue form per instantiation: fewer live registers, no run-time test); both forms can also write the
 // consumer's act(GroupNorm(y)) from their LDS tiles (ConvArgs::yn, 16 x 16 maps)
-template <bool PACKED>
+template <bool PACKED, typename T_ = __bf16>
 __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     using C = ConvDmaCfg;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW;
-    using T = __bf16;
+    using T = T_;                      // __bf16 or f16_t: same layouts, same instruction counts
     constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     conv_epilogue<T, 16, TW, 4, WN, WN, EpiNoHook, false, (PACKED ? 2 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, 0, EpiNoHook(), true, keep_tab, C::BN);
     if (a.yn != nullptr) {
         float* tab = (float*)(smem + KEEP_OFF + G::keep_bytes(1, C::BN));
-        if constexpr (PACKED) gn_out_tail_packed<C::NTHREADS, C::WAVES_N, C::BN>(a, img0, n0, smem, keep_tab, tab, tid);
+        if constexpr (PACKED) gn_out_tail_packed<T, C::NTHREADS, C::WAVES_N, C::BN>(a, img0, n0, smem, keep_tab, tab, tid);
         else gn_out_tail<T, C::NTHREADS, G, C::WAVES_N, WN, C::BN>(a, img0, 1, n0, smem, keep_tab, tab, tid);
     }
     gn_arrive<C::NTHREADS>(a, img0, 1, a.Hout * a.Wout, (int*)smem, tid);       // the consumer's GroupNorm finalised by the image's last workgroup (when asked: fin_cnt)

@@ -46,10 +46,10 @@ struct GemmCfg {
 };
 
 // the workgroup's work: block `bid` of the launch described by `a` (a kernel may hold two launches: tools/experiments/conv_gemm_pair_kernel.h)
-template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, typename T_ = __bf16>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid, char* smem) {
     using C = GemmCfg<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
-    using T = __bf16;
+    using T = T_;
     constexpr int BN = C::BN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
 
     const int tid = threadIdx.x;
@@ -196,10 +196,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid,
     conv_epilogue<T, TH, TW, WM, WN, (TH * TW == 64 ? 2 : C::EPI_NJ), EpiNoHook, false, ((TH * TW) % 64 == 0 && TW == 16 && WM == 4 && WN % 4 == 0 && TH * TW != 64 ? 1 : 0)>(a, acc, smem, true, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img);
 }
 
-template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, typename T_ = __bf16>
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_gemm_body<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>(a, blockIdx.x, smem);
+    conv_gemm_body<TH, TW, NI, WAVES_M, WAVES_N, WM, WN, T_>(a, blockIdx.x, smem);
 }
 
 }  // namespace wdm

@@ -236,8 +236,35 @@ template <> struct TI<__bf16> {
     __device__ static __forceinline__ uint4 pack(const float* f) {
         return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
+    __device__ static __forceinline__ float raw16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
     __device__ static __forceinline__ float ld(const void* p, long long i) { return bf16_to_f32(((const bf16_raw*)p)[i]); }
     __device__ static __forceinline__ void st(void* p, long long i, float v) { ((bf16_raw*)p)[i] = f32_to_bf16(v); }
+};
+
+// IEEE half ("f16" mode): the bf16 kernels on fp16 operands.  Same instruction counts as bf16 -- v_cvt_f32_f16 (SDWA for the upper half) per unpacked element,
+// one v_cvt_pk_f16_f32 (RNE) per packed pair, v_mfma_f32_16x16x32_f16 at the bf16 MFMA's rate -- with three more mantissa bits and a range of +-65504.
+typedef _Float16 f16_t;
+template <> struct TI<f16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ void unpack(const uint4& u, float* f) {
+        typedef f16_t v8h __attribute__((ext_vector_type(8)));
+        typedef float v8f __attribute__((ext_vector_type(8)));
+        const v8f v = __builtin_convertvector(__builtin_bit_cast(v8h, u), v8f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = v[e];
+    }
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) {      // one v_cvt_pk_f16_f32 (RNE)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef f16_t v2h __attribute__((ext_vector_type(2)));
+        const v2f v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2h));
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    __device__ static __forceinline__ float raw16_to_f32(unsigned short v) { return (float)__builtin_bit_cast(f16_t, v); }
+    __device__ static __forceinline__ float ld(const void* p, long long i) { return (float)((const f16_t*)p)[i]; }
+    __device__ static __forceinline__ void st(void* p, long long i, float v) { ((f16_t*)p)[i] = (f16_t)v; }
 };
 
 __device__ __forceinline__ float silu_f(float v) {
@@ -279,6 +306,10 @@ template <> struct TI<f32x3_t> : TI<float> {};
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
 template <> __device__ __forceinline__ void mma16<__bf16>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<f16_t>(f32x4& acc, const uint4& a, const uint4& b) {
+    typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -660,7 +691,7 @@ __host__ __device__ __forceinline__ bool conv_epilogue_can_pack(const AT& a) {
 #endif
 }
 constexpr int EPI_PACK_TILE = 64 * 128;      // LDS bytes per wave
-template <int TH, int TW, int WN, class Hook = EpiNoHook, class AT = ConvArgs>
+template <typename T, int TH, int TW, int WN, class Hook = EpiNoHook, class AT = ConvArgs>
 __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4][WN], int jp, char* smem, int wave, int lane_, int wave_m, int wave_n, int img0, int oy0,
                                                      int ox0, int n0, int tile_in_img, int phase, Hook hook, bool call_hook, float4* keep_tab = nullptr, int keep_bn = 0) {
     constexpr int EROWS = 64, ROWB = 128;
@@ -691,8 +722,8 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = acc[i][jp + j];
                 uint2 pk;
-                pk.x = TI<__bf16>::pack2(__builtin_fmaf(v[0], a.alpha, ad.x), __builtin_fmaf(v[1], a.alpha, ad.y));
-                pk.y = TI<__bf16>::pack2(__builtin_fmaf(v[2], a.alpha, ad.z), __builtin_fmaf(v[3], a.alpha, ad.w));
+                pk.x = TI<T>::pack2(__builtin_fmaf(v[0], a.alpha, ad.x), __builtin_fmaf(v[1], a.alpha, ad.y));
+                pk.y = TI<T>::pack2(__builtin_fmaf(v[2], a.alpha, ad.z), __builtin_fmaf(v[3], a.alpha, ad.w));
                 *(uint2*)(tp + wr + i * (16 * ROWB)) = pk;
             }
         }
@@ -738,7 +769,7 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
 #pragma unroll
             for (int k = 0; k < 8; ++k) va[h][k] = ((u ^ k) << 4) | ((((e >> 2) ^ h)) << 3) | ((e & 3) << 1);
         auto val = [&](int r) __attribute__((always_inline)) {
-            return __uint_as_float((unsigned)*(const unsigned short*)(tp + r * ROWB + va[(r >> 3) & 1][r & 7]) << 16);
+            return TI<T>::raw16_to_f32(*(const unsigned short*)(tp + r * ROWB + va[(r >> 3) & 1][r & 7]));
         };
         const float K = val(0);
         float s1 = 0.f, s2 = 0.f;
@@ -784,12 +815,12 @@ __device__ __forceinline__ void conv_epilogue(const AT& a, f32x4 (&acc)[WM][WN],
     // 3.5 % slower end to end and is gone; conv_epilogue_packed below keeps the column pass and drops the fp32 round trips instead.)
     // PACK = 1: the packed form when the arguments allow it (run-time test), 2: always (the launcher has tested: no fp32 form in the kernel at all)
     if constexpr (PACK != 0) {
-        static_assert(TI<T>::VEC == 8 && WM == 4 && (WN % 4) == 0 && TW == 16 && (TH * TW) % 64 == 0, "packed epilogue: bf16, 64-row wave tiles of a 16-wide pixel tile");
+        static_assert(TI<T>::VEC == 8 && WM == 4 && (WN % 4) == 0 && TW == 16 && (TH * TW) % 64 == 0, "packed epilogue: 16-bit tiles, 64-row wave tiles of a 16-wide pixel tile");
         if (PACK == 2 || (keep_tab == nullptr && conv_epilogue_can_pack(a))) {
             if (entry_barrier) __syncthreads();
 #pragma unroll
             for (int jp = 0; jp < WN; jp += 4)
-                conv_epilogue_packed<TH, TW, WN, Hook, AT>(a, acc, jp, smem, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, jp == 0, keep_tab, keep_bn);
+                conv_epilogue_packed<T, TH, TW, WN, Hook, AT>(a, acc, jp, smem, wave, lane, wave_m, wave_n, img0, oy0, ox0, n0, tile_in_img, phase, hook, jp == 0, keep_tab, keep_bn);
             return;
         }
     }
@@ -1148,5 +1179,6 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
 int launch_conv_bf16(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32(const ConvArgs& a, int mode, hipStream_t s);
 int launch_conv_f32x3(const ConvArgs& a, int mode, hipStream_t s);
+int launch_conv_f16(const ConvArgs& a, int mode, hipStream_t s);
 
 }  // namespace wdm

@@ -41,11 +41,11 @@ struct ConvUp4Cfg {
     static_assert(EPI_BYTES <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int TILE, int NI_, int WN_ = 4>
+template <int TILE, int NI_, int WN_ = 4, typename T_ = __bf16>
 __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
     using C = ConvUp4Cfg<TILE, NI_, WN_>;
     constexpr int NI = C::NI;
-    using T = __bf16;
+    using T = T_;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 

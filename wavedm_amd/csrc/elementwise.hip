@@ -154,14 +154,14 @@ int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patc
     if (n <= 0 || p <= 0 || nch <= 0 || c_off < 0 || c_off + nch > c_total) WDM_FAIL(WDM_EINVAL, "pack_channels: bad arguments");
     if (patches == nullptr && (p != H || p != W)) WDM_FAIL(WDM_EINVAL, "pack_channels: identity patch list needs p == H == W");
     if (p <= PACK_MAX_P && nch <= PACK_MAX_CH && (long long)n * p < 2147483647LL) {
-        if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_channels_rows_kernel<__bf16>, dim3(n * p), dim3(256), 0, s, src, nch, H, W, patches, p, (__bf16*)x96, c_total, c_off);
+        if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_channels_rows_kernel<H16>, dim3(n * p), dim3(256), 0, s, src, nch, H, W, patches, p, (H16*)x96, c_total, c_off));
         else hipLaunchKernelGGL(pack_channels_rows_kernel<float>, dim3(n * p), dim3(256), 0, s, src, nch, H, W, patches, p, (float*)x96, c_total, c_off);
         WDM_HIP(hipGetLastError());
         return WDM_OK;
     }
     const long long total = (long long)n * p * p * nch;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_channels_kernel<__bf16>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (__bf16*)x96, c_total, c_off);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_channels_kernel<H16>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (H16*)x96, c_total, c_off));
     else hipLaunchKernelGGL(pack_channels_kernel<float>, dim3(g), dim3(256), 0, s, src, nch, H, W, patches, n, p, (float*)x96, c_total, c_off);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -288,7 +288,7 @@ int k_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int 
     const long long total = (long long)B * C * H * W;
     if (total <= 0) WDM_FAIL(WDM_EINVAL, "nchw_to_nhwc: empty tensor");
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(g), dim3(256), 0, s, src, (__bf16*)dst, B, C, H * W);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<H16>, dim3(g), dim3(256), 0, s, src, (H16*)dst, B, C, H * W));
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, B, C, H * W);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -297,7 +297,7 @@ int k_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int 
     const long long total = (long long)B * C * H * W;
     if (total <= 0) WDM_FAIL(WDM_EINVAL, "nhwc_to_nchw: empty tensor");
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)src, dst, B, C, H * W);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<H16>, dim3(g), dim3(256), 0, s, (const H16*)src, dst, B, C, H * W));
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, dst, B, C, H * W);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -436,12 +436,12 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float4* __
 }
 
 int k_gn_partial(const Tens& x, int B, float* stats, int nslab, int dtype, hipStream_t s) {
-    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const int vec = is_h16(dtype) ? 8 : 4;
     const int HW = x.H * x.W;
     if (x.C % vec) WDM_FAIL(WDM_EINVAL, "groupnorm: channel count %d must be a multiple of %d", x.C, vec);
     const int cols = x.C / vec;
     const dim3 grid(nslab, B, (cols + 255) / 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nslab, (float4*)stats);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(gn_partial_kernel<H16>, grid, dim3(256), 0, s, (const H16*)x.p, x.xs, x.C, HW, nslab, (float4*)stats));
     else hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nslab, (float4*)stats);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -468,7 +468,7 @@ int k_gn_finalize(int B, int HW, const float* st0, int nslab0, int C0, const flo
 
 // y (dense, C0 + C1 channels per pixel) = act(GroupNorm([x0 | x1])) from the tensors' partial statistics, one launch (gn_finalize_apply_kernel)
 bool gn_fused_pass_eligible(int C0, int C1, int dtype) {
-    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const int vec = is_h16(dtype) ? 8 : 4;
     const int C = C0 + C1, gw = C / 32;
     // a 16-byte vector must not straddle the seam of the concat, and the four groups of a workgroup must be whole vectors
     return C % 32 == 0 && gw <= 64 && C0 % vec == 0 && C1 % vec == 0 && (4 * gw) % vec == 0;
@@ -480,14 +480,14 @@ int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0,
     const dim3 grid(8, B);
     const bool prof = prof_enabled();
     if (prof) {
-        const double es = dtype == WDM_BF16 ? 2.0 : 4.0;
+        const double es = is_h16(dtype) ? 2.0 : 4.0;
         char name[64];
         snprintf(name, sizeof(name), "gn_finalize_apply_kernel|%dx%d C=%d%s", x0.H, x0.W, C, silu ? " silu" : "");
         prof_begin(s, name, 0.0, 2.0 * B * HW * C * es + 16.0 * B * (nslab0 * (double)C0 + (st1 ? nslab1 * (double)C1 : 0.0)));
     }
-    if (dtype == WDM_BF16)
-        hipLaunchKernelGGL(gn_finalize_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
-                           nw.b, eps, (const __bf16*)x0.p, x0.xs, (const __bf16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (__bf16*)y, silu);
+    if (is_h16(dtype))
+        WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(gn_finalize_apply_kernel<H16>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
+                           nw.b, eps, (const H16*)x0.p, x0.xs, (const H16*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (H16*)y, silu));
     else
         hipLaunchKernelGGL(gn_finalize_apply_kernel<float>, grid, dim3(256), 0, s, (const float4*)st0, nslab0, C0, (const float4*)(st1 ? st1 : st0), st1 ? nslab1 : 1, C, HW, nw.g,
                            nw.b, eps, (const float*)x0.p, x0.xs, (const float*)(x1 ? x1->p : x0.p), x1 ? x1->xs : x0.xs, (float*)y, silu);
@@ -516,10 +516,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int sc_ld, void* y, int y_stride, int y_choff, int silu, int dtype,
                hipStream_t s) {
     const int HW = x.H * x.W;
-    const int vec = dtype == WDM_BF16 ? 8 : 4;
+    const int vec = is_h16(dtype) ? 8 : 4;
     const long long nvec = (long long)B * HW * (x.C / vec);
     const int g = nblocks(nvec, 256) > 16384 ? 16384 : nblocks(nvec, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x.p, x.xs, x.C, HW, nvec, scale, shift, sc_ld, (__bf16*)y + y_choff, y_stride, silu);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(gn_apply_kernel<H16>, dim3(g), dim3(256), 0, s, (const H16*)x.p, x.xs, x.C, HW, nvec, scale, shift, sc_ld, (H16*)y + y_choff, y_stride, silu));
     else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x.p, x.xs, x.C, HW, nvec, scale, shift, sc_ld, (float*)y + y_choff, y_stride, silu);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 int k_softmax_rows(const float* S, void* P, long long rows, int n, int dtype, hipStream_t s) {
     if (n % 64 || n > 512 || n <= 0) WDM_FAIL(WDM_EINVAL, "softmax: row length %d must be a multiple of 64 and <= 512", n);
     const int g = (int)((rows + 3) / 4);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(softmax_rows_kernel<__bf16>, dim3(g), dim3(256), 0, s, S, (__bf16*)P, rows, n);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(softmax_rows_kernel<H16>, dim3(g), dim3(256), 0, s, S, (H16*)P, rows, n));
     else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(g), dim3(256), 0, s, S, (float*)P, rows, n);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
@@ -633,12 +633,13 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
     const int rows_span = zero_tail ? rows_total - row_off : cout;
     const long long total = (long long)rows_span * cin_dst * k * k;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, cin_dst, k * k, (__bf16*)dst, rows_total, row_off, rows_span);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_conv_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, cin_dst, k * k, (H16*)dst, rows_total, row_off, rows_span));
     else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, cin_dst, k * k, (float*)dst, rows_total, row_off, rows_span);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
-__global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restrict__ w, int cout, int cin, __bf16* __restrict__ dst, int rows_total) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total) {
     const long long total = (long long)9 * rows_total * cin;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id & 31);
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restri
         const int tap = (int)((id / ((long long)32 * rows_total)) % 9);
         const int slab = (int)(id / ((long long)32 * rows_total * 9));
         const float v = o < cout ? w[((long long)o * cin + slab * 32 + c) * 9 + tap] : 0.f;
-        dst[id] = (__bf16)v;
+        TI<T>::st(dst, id, v);
     }
 }
 // f32x3 mode (conv_dmax3_kernel.h): OIHW f32 3x3 -> [tap][rows_total][cin] with every 16-channel group (64 bytes) already split and laid out as the kernel's
@@ -684,13 +685,14 @@ int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_t
     if (cin % 32) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 32", cin);
     const long long total = (long long)9 * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    hipLaunchKernelGGL(pack_conv_sm_kernel, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst, rows_total);
+    WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_conv_sm_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (H16*)dst, rows_total));
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
 // Upsample in sub-pixel form (conv_up4_kernel.h): OIHW f32 3x3 -> [phase = 2 py + px][dy'][dx'][rows_total][cin] bf16, the taps of the
 // upsampled grid that fall on the same low-resolution pixel summed in fp32:  py = 0: {w0}, {w1 + w2};  py = 1: {w0 + w1}, {w2}
-__global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__ w, int cout, int cin, __bf16* __restrict__ dst, int rows_total) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total) {
     const long long total = (long long)16 * rows_total * cin;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int ci = (int)(id % cin);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__
             for (int ty = y0; ty <= y1; ++ty)
                 for (int tx = x0; tx <= x1; ++tx) v += p[ty * 3 + tx];
         }
-        dst[id] = (__bf16)v;
+        TI<T>::st(dst, id, v);
     }
 }
 // f32x3 mode (conv_up4x3_kernel.h): the same 16 pre-summed taps (fp32 sums), every 16-channel group split and laid out as [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
@@ -750,7 +752,7 @@ int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total
     }
     const long long total = (long long)16 * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    hipLaunchKernelGGL(pack_up4_kernel, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (__bf16*)dst, rows_total);
+    WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_up4_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (H16*)dst, rows_total));
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
@@ -766,8 +768,19 @@ __global__ __launch_bounds__(256) void pad_channels2_kernel(const T* __restrict_
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s) {
     const long long total = rows * Cp;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    if (dtype == WDM_BF16) hipLaunchKernelGGL(pad_channels2_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, C, Cp, (__bf16*)y, total);
+    if (is_h16(dtype)) WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pad_channels2_kernel<H16>, dim3(g), dim3(256), 0, s, (const H16*)x, C, Cp, (H16*)y, total));
     else hipLaunchKernelGGL(pad_channels2_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, C, Cp, (float*)y, total);
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+__global__ __launch_bounds__(256) void flag_out_of_range_kernel(const float* __restrict__ x, long long n, float limit, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) bad = bad || !(fabsf(x[id]) <= limit);      // NaN compares false
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1;          // every writer stores the same value: no atomic needed
+}
+int k_flag_out_of_range(const float* x, long long n, float limit, int* flag_dev, hipStream_t s) {
+    const int g = nblocks(n, 256) > 1024 ? 1024 : nblocks(n, 256);
+    hipLaunchKernelGGL(flag_out_of_range_kernel, dim3(g), dim3(256), 0, s, x, n, limit, flag_dev);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }

@@ -183,9 +183,8 @@ __device__ __forceinline__ void gn_out_tail(const AT& a, int img0, int nimg, int
 // The same tail behind the bf16-tile epilogue (conv_epilogue_packed; 16 x 16 maps on 256 x 128 tiles: ONE image x 128 columns, one pass): wave (wm, wn) keeps its 64 rows x
 // 64 columns as the swizzled bf16 tile of that epilogue -- row r = 128 bytes, 16-byte unit u in slot u ^ (r & 7), the unit's 8-byte halves swapped when r & 8 --,
 // i.e. exactly the values stored to y; statistics table, group reduction and per-element arithmetic are those of gn_out_tail: the same bits.
-template <int NTHREADS, int WAVES_N, int BN, class AT>
+template <typename T, int NTHREADS, int WAVES_N, int BN, class AT>
 __device__ __forceinline__ void gn_out_tail_packed(const AT& a, int img0, int n0, char* smem, const float4* keep_tab, float* tab, int tid) {
-    using T = __bf16;
     constexpr int NW = NTHREADS / 64, HW = 256, SPT = 4, bn = BN;
     const int lane = tid & 63, wave = tid >> 6;
     const int gw = a.Cout >> 5;

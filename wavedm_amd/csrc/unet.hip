@@ -47,6 +47,7 @@ struct wdm_unet {
     std::vector<ParamSlot> params;
     std::map<std::string, int> index;
     size_t packed_bytes = 0;
+    size_t range_flag_off = 0;      // WDM_F16 only
     char* packed = nullptr;
     bool all_loaded = false;
     int temb_ch = 0, temb_rows = 0;   // rows of the concatenated temb_proj matrix
@@ -197,7 +198,7 @@ int wdm_unet::build() {
             for (int b = 0; b <= nrb; ++b) up_attn[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != 0) {
             up_us[l] = add_conv("up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3, 0, false);
-            if ((cfg.dtype == WDM_BF16 || cfg.dtype == WDM_F32X3) && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h / conv_up4x3_kernel.h, next to the 3x3 ones
+            if ((is_h16(cfg.dtype) || cfg.dtype == WDM_F32X3) && block_in % 32 == 0 && block_in >= 128) {       // sub-pixel taps for conv_up4_kernel.h / conv_up4x3_kernel.h, next to the 3x3 ones
                 up_us[l].up4_off = take((size_t)16 * up_us[l].rows_pad * block_in * dsize(cfg.dtype));
                 params[index["up." + std::to_string(l) + ".upsample.conv.weight"]].up4_off = up_us[l].up4_off;
             }
@@ -208,6 +209,7 @@ int wdm_unet::build() {
     conv_out = add_conv("conv_out", block_in, cfg.out_ch, 3);
 
     // all temb_proj Linear layers concatenated into one [sum(cout)][temb_ch] fp32 matrix: one GEMV launch per step
+    if (cfg.dtype == WDM_F16) range_flag_off = take(256);      // device int the weight loader's fp16 range check writes (wdm_unet_load_param)
     temb_w_off = take((size_t)temb_rows * temb_ch * 4);
     temb_b_off = take((size_t)temb_rows * 4);
     int row = 0;
@@ -390,7 +392,7 @@ int wdm_destroy(wdm_handle* h) { delete h; return WDM_OK; }
 int wdm_unet_create(wdm_handle* h, const wdm_unet_config* cfg, wdm_unet** out) {
     if (!cfg || !out) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: null argument");   // h may be NULL for host-only layout queries
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad level count");
-    if (cfg->dtype != WDM_BF16 && cfg->dtype != WDM_F32 && cfg->dtype != WDM_F32X3) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
+    if (!dtype_valid(cfg->dtype)) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: bad dtype");
     if (!cfg->resamp_with_conv) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resamp_with_conv=False is not supported");
     if (cfg->ch % 32 || cfg->in_channels < 1) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: ch must be a multiple of 32");
     if (cfg->resolution % (8 << (cfg->n_levels - 1))) WDM_FAIL(WDM_EINVAL, "wdm_unet_create: resolution %d too small for %d levels (coarsest level must be a multiple of 8)", cfg->resolution, cfg->n_levels);
@@ -433,6 +435,17 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     hipStream_t s = (hipStream_t)stream;
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
+        if (u->cfg.dtype == WDM_F16) {
+            // fp16 operands: a weight outside +-65504 (or not finite) would become inf in the packed matrix -- refuse it here, loudly.  The one place this
+            // entry point waits for the stream (set-up path; the sampling path never does)
+            int* flag = (int*)(u->packed + u->range_flag_off);
+            int host_flag = 0;
+            WDM_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+            WDM_TRY(k_flag_out_of_range(dev_src, numel, 65504.0f, flag, s));
+            WDM_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            WDM_HIP(hipStreamSynchronize(s));
+            if (host_flag) WDM_FAIL(WDM_EINVAL, "parameter '%s': a value lies outside the fp16 range (|w| <= 65504, finite) -- use WDM_BF16 or WDM_F32X3 for this checkpoint", name);
+        }
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
         if (p.sm_off) WDM_TRY(k_pack_conv_sm(dev_src, cout, cin, u->packed + p.sm_off, p.rows_total, s, u->cfg.dtype));
         if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s, u->cfg.dtype));

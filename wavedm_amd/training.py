@@ -27,7 +27,7 @@ class Trainer:
         if self.device.type != "cuda":
             raise RuntimeError("wavedm_amd.Trainer runs on MI355X only (no CPU path)")
         self._dtype_code = resolve_dtype(config, dtype)
-        if self._dtype_code == _lib.WDM_F32X3:               # training has two modes: f32x3 (an inference mode) trains in exact fp32
+        if self._dtype_code in (_lib.WDM_F32X3, _lib.WDM_F16):      # training has two modes: f32x3 / f16 (inference modes) train in exact fp32
             self._dtype_code = _lib.WDM_F32
         opt = getattr(config, "optim", None)
         self.lr = float(lr if lr is not None else getattr(opt, "lr", 4e-5))

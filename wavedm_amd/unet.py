@@ -6,9 +6,9 @@ libwavedm_hip.so.
   `load_state_dict(strict=True)`;
 * `forward(x, t)`: x (B, 96, R, R) fp32 NCHW on the GPU, t (n,) float with n in {1, B}
   -> (B, 3, R, R) fp32 NCHW, exactly the reference call;
-* compute dtype: `config.model.hip_dtype` / env WAVEDM_DTYPE in {"bf16" (default: throughput), "f32" (exact-fp32 parity mode),
-  "f32x3" (fast parity mode: fp32 tensors, every product as three bf16 MFMAs on hi/lo-split operands)}.
-  f32 is the parity mode (exact-fp32 MFMA), bf16 the throughput mode (bf16 MFMA, fp32 accumulate).
+* compute dtype: `config.model.hip_dtype` / env WAVEDM_DTYPE in {"bf16" (default: throughput), "f16" (the bf16 kernels on fp16 operands:
+  the bf16 speed with three more mantissa bits, weights must lie inside +-65504), "f32" (exact-fp32 parity mode), "f32x3" (fast parity mode:
+  fp32 tensors, every product as three bf16 MFMAs on hi/lo-split operands)}.
 
 The parameter tree is generated from the library's own parameter table (wdm_unet_param_info), so
 Python and C++ cannot disagree about names or shapes."""
@@ -53,7 +53,7 @@ def _make_config(config, dtype_code):
 def resolve_dtype(config=None, dtype=None):
     name = dtype or getattr(getattr(config, "model", None), "hip_dtype", None) or os.environ.get("WAVEDM_DTYPE", "bf16")
     if name not in _lib.DTYPES:
-        raise ValueError(f"unknown compute dtype {name!r} (use 'bf16', 'f32' or 'f32x3')")
+        raise ValueError(f"unknown compute dtype {name!r} (use 'bf16', 'f16', 'f32' or 'f32x3')")
     return _lib.DTYPES[name]
 
 
@@ -101,7 +101,7 @@ class DiffusionUNet(nn.Module):
         self.ch = int(config.model.ch)
         self.temb_ch = self.ch * 4
         self._dtype_code = resolve_dtype(config, dtype)
-        self._torch_dtype = torch.bfloat16 if self._dtype_code == _lib.WDM_BF16 else torch.float32
+        self._torch_dtype = {_lib.WDM_BF16: torch.bfloat16, _lib.WDM_F16: torch.float16}.get(self._dtype_code, torch.float32)
         L = _lib.lib()
         self._cfg = _make_config(config, self._dtype_code)
         u = C.c_void_p()
