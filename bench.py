@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--ddim-steps", type=int, default=100)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32x3"])
     ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c4"],
                     help="c1: BASELINE configs[1] (default, the headline metric); c2: 128x128 patches, batch 256; "
                          "c4: whole 480x720 images, 45 stitched patches each, 50 DDIM steps (informational extra runs)")
@@ -229,7 +229,7 @@ def main():
             log(f"[shape] {e['kernel']:<64s} n {e['launches']:5d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  "
                 f"{100 * e['ms'] / tot_ms:5.1f}%")
         dom = rep[0]
-        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "f16") else MFMA_F32_PEAK_TFLOPS
         ach = dom["flops"] / dom["ms"] / 1e9
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
@@ -428,14 +428,15 @@ def main():
         a.sampling_timesteps = 10
         modes = {}
         headline_rel = None
-        for name in ("f32x3", "f32"):
+        ref32 = None                 # exact-f32 HIP results of crops 0-3 of the timed batch, full length: the yardstick of every faster mode below
+        for name in ("f32", "f16", "f32x3"):
             df = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=name)
             df.model.load_state_dict(sd, strict=True)
-            if name == "f32x3":
-                # the tolerance-conformant mode as a first-class number: the SAME 64 crops as the headline, ALL ddim steps,
-                # 1 warm-up pass + 3 timed passes, and its own roofline leg (events around every conv launch of one more pass)
+            if name != "f32":
+                # the tolerance-conformant modes as first-class numbers: the SAME 64 crops as the headline, ALL ddim steps,
+                # 1 warm-up pass + 3 timed passes, and their own roofline leg (events around every conv launch of one more pass)
                 a.sampling_timesteps = args.ddim_steps
-                df.restore_batch(rainy, x_T)
+                _, xl_m, x0_m = df.restore_batch(rainy, x_T)
                 torch.cuda.synchronize()
                 tq = time.perf_counter()
                 for _ in range(3):
@@ -445,6 +446,8 @@ def main():
                 ips = B / tp_
                 m = {"dtype": name, "value": round(ips, 3), "unit": "img/s", "ms_per_step": round(tp_ * 1e3, 2), "steps": args.ddim_steps, "passes": 3, "warmup": 1,
                      "sample": f"the headline's {B} crops, all {args.ddim_steps} DDIM steps, mean of 3 passes after 1 warm-up pass", "tolerance": 1e-3}
+                if ref32 is not None:
+                    m["rel_linf_vs_f32_full_length"] = float(f"{max(rel(xl_m[:4].cpu(), ref32[0]), rel(x0_m[:4].cpu(), ref32[1])):.3e}")
                 _lib.prof_enable(True)
                 df.restore_batch(rainy, x_T)
                 torch.cuda.synchronize()
@@ -459,14 +462,16 @@ def main():
                 rep3 = sorted(agg3.values(), key=lambda e: -e["ms"])
                 tot3 = sum(e["ms"] for e in rep3)
                 for e in rep3[:8]:
-                    log(f"[bench] f32x3 {e['kernel']:<40s} launches {e['launches']:6d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  {100 * e['ms'] / tot3:5.1f}%")
+                    log(f"[bench] {name} {e['kernel']:<40s} launches {e['launches']:6d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  {100 * e['ms'] / tot3:5.1f}%")
                 d3 = rep3[0]
-                # one fp32 product = two full-rate bf16 MFMAs with the split operands, four times the MFMA time of a bf16 product: 2500 / 4
-                pk3 = MFMA_BF16_PEAK_TFLOPS / 4
+                # f32x3: one fp32 product = two full-rate bf16 MFMAs with the split operands, four times the MFMA time of a bf16 product: 2500 / 4;
+                # f16: v_mfma_f32_16x16x32_f16 runs at the bf16 MFMA's rate
+                pk3 = MFMA_BF16_PEAK_TFLOPS / 4 if name == "f32x3" else MFMA_BF16_PEAK_TFLOPS
                 m["roofline"] = {"bound": "mfma", "kernel": d3["kernel"], "launches": d3["launches"], "avg_launch_us": round(d3["ms"] / d3["launches"] * 1e3, 2),
-                                 "achieved": round(d3["flops"] / d3["ms"] / 1e9, 2), "peak": pk3, "unit": "TFLOP/s (fp32-equivalent: 2 M N K per product)",
+                                 "achieved": round(d3["flops"] / d3["ms"] / 1e9, 2), "peak": pk3,
+                                 "unit": "TFLOP/s (fp32-equivalent: 2 M N K per product)" if name == "f32x3" else "TFLOP/s",
                                  "frac": round(d3["flops"] / d3["ms"] / 1e9 / pk3, 4), "all_conv_tflops": round(sum(e["flops"] for e in rep3) / tot3 / 1e9, 2),
-                                 "conv_ms_per_pass": round(tot3, 2), "profile": "profiles/r04_kernel_stats_f32x3.md"}
+                                 "conv_ms_per_pass": round(tot3, 2), "profile": f"profiles/r05_kernel_stats_{name}.md"}
                 a.sampling_timesteps = 10
             else:
                 rp, xp = P.synthetic_batch(B, patch_px=256, seed=63)
@@ -486,12 +491,20 @@ def main():
                 a.sampling_timesteps = args.ddim_steps
                 _, xl32, x032 = df.restore_batch(rainy[:4].contiguous(), x_T[:4].contiguous())
                 a.sampling_timesteps = 10
-                headline_rel = max(rel(xs_last[:4].cpu(), xl32.cpu()), rel(x0[:4].cpu(), x032.cpu()))
+                ref32 = (xl32.cpu(), x032.cpu())
+                headline_rel = max(rel(xs_last[:4].cpu(), ref32[0]), rel(x0[:4].cpu(), ref32[1]))
             modes[name] = m
             log(f"[bench] parity mode {name}: {ips:.2f} img/s {m}")
             del df
             torch.cuda.empty_cache()
-        parity_mode = modes["f32x3"]
+        # the parity mode = the FASTEST mode whose full-length deviation measured inside north_star's 1e-3 in this very run (crops 0-3 of the timed batch, all DDIM
+        # steps, against the exact-f32 HIP path); the other conformant mode rides along
+        conformant = [m for m in (modes["f16"], modes["f32x3"]) if m.get("rel_linf_vs_f32_full_length", 1.0) <= 1e-3]
+        parity_mode = dict(max(conformant, key=lambda m: m["value"]) if conformant else modes["f32x3"])
+        parity_mode["selected_by"] = ("fastest mode with rel_linf_vs_f32_full_length <= 1e-3 in this run" if conformant else
+                                      "no fast mode measured <= 1e-3 in this run: f32x3 reported, see its rel_linf_vs_f32_full_length")
+        parity_mode["f32x3"] = modes["f32x3"]
+        parity_mode["f16"] = modes["f16"]
         parity_mode["exact_f32"] = modes["f32"]
         if headline_rel is not None:
             parity_mode["rel_linf_bf16_vs_f32_headline"] = float(f"{headline_rel:.3e}")

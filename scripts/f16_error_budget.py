@@ -43,7 +43,8 @@ def conv(sd, name, x, stride=1, padding=0):
 
 
 def resnet_block(sd, name, x, temb):
-XX, O.silu(O.group_norm(sd, name + ".norm1", x)), padding=1)
+    S = (lambda v: rnd(v)) if ("S" in SITES and on(name)) else (lambda v: v)
+    h = conv(sd, name + ".conv1", O.silu(O.group_norm(sd, name + ".norm1", x)), padding=1)
     h = S(h + O.linear(sd, name + ".temb_proj", O.silu(temb))[:, :, None, None])
     h = conv(sd, name + ".conv2", O.silu(O.group_norm(sd, name + ".norm2", h)), padding=1)
     if (name + ".nin_shortcut.weight") in sd:

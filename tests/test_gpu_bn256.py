@@ -46,20 +46,22 @@ def _modes(f, modes=("0", "2", "1")):
 
 @pytest.mark.parametrize("cin,cout,B,H", [(128, 256, 2, 32), (256, 256, 3, 32), (768, 256, 1, 32), (512, 512, 3, 16), (1280, 512, 2, 16), (96, 256, 1, 48),
                                           (128, 128, 2, 64), (96, 128, 1, 64), (384, 128, 1, 64), (128, 128, 3, 32), (64, 384, 1, 32)])
-def test_conv_bits(gu, cin, cout, B, H):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv_bits(gu, dtype, cin, cout, B, H):
     w = gu.seeded((cout, cin, 3, 3), 100) / (cin * 9) ** 0.5
     b = gu.seeded((cout,), 200) * 0.1
     x = gu.seeded((B, cin, H, H), 316)
-    ys = _modes(lambda: gu.conv(w, b, 0, x, "bf16"))
+    ys = _modes(lambda: gu.conv(w, b, 0, x, dtype))
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
     ref = torch.nn.functional.conv2d(x, w, b, padding=1)
-    assert float((ys[1] - ref).abs().max() / ref.abs().max()) <= gu.TOL["bf16"]
+    assert float((ys[1] - ref).abs().max() / ref.abs().max()) <= gu.TOL[dtype]
 
 
 @pytest.mark.parametrize("c0,c1,cout,B,H", [(256, 0, 256, 2, 32), (256, 256, 256, 2, 32), (512, 256, 256, 1, 32), (512, 0, 512, 3, 16), (512, 512, 512, 2, 16),
                                             (768, 512, 512, 1, 16), (128, 0, 128, 2, 64), (128, 128, 128, 1, 64), (256, 128, 128, 1, 64), (128, 0, 128, 3, 32)])
-def test_resblock_bits(gu, c0, c1, cout, B, H):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_resblock_bits(gu, dtype, c0, c1, cout, B, H):
     """conv1 (prologue over the concat, temb, statistics) and conv2 (statistics, residual or the fused 1x1 shortcut) through every tiling."""
     cin = c0 + c1
     shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,), "temb_proj.weight": (cout, 512),
@@ -71,7 +73,7 @@ def test_resblock_bits(gu, c0, c1, cout, B, H):
     x0 = gu.seeded((B, c0, H, H), 5)
     x1 = gu.seeded((B, c1, H, H), 7) if c1 else None
     t = gu.seeded((B, 512), 6)
-    ys = _modes(lambda: gu.resblock(sd, "rb", x0, x1, t, "bf16"))
+    ys = _modes(lambda: gu.resblock(sd, "rb", x0, x1, t, dtype))
     assert torch.isfinite(ys[0]).all()
     for y in ys[1:]:
         assert torch.equal(ys[0], y)

@@ -13,6 +13,7 @@
 #include <vector>
 #include "conv_dma_kernel.h"
 #include "conv_dma256_kernel.h"
+#include "conv_dma4w_kernel.h"
 #include "conv_dmap_kernel.h"
 #include "conv_dma2_kernel.h"
 using namespace wdm;
@@ -57,6 +58,10 @@ int main(int argc, char** argv) {
         {"t512x128F", conv_dma256_kernel<8, 1, 4, 8, 32, false, false>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
         {"t512x128S", conv_dma256_kernel<8, 1, 4, 8, 32, true, true>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
         {"t512x128FS", conv_dma256_kernel<8, 1, 4, 8, 32, false, true>, ConvDma256Cfg<8, 1, 4, 8, 32>::LDS_BYTES, 32, 128, 0},
+        {"w4_256x256", conv_dma4w_kernel<2, 2, 16, true>, ConvDma4wCfg<2, 2, 16>::LDS_BYTES, 16, 256, 0, 256},
+        {"w4_256x256F", conv_dma4w_kernel<2, 2, 16, false>, ConvDma4wCfg<2, 2, 16>::LDS_BYTES, 16, 256, 0, 256},
+        {"w4_512x128", conv_dma4w_kernel<4, 1, 32, true>, ConvDma4wCfg<4, 1, 32>::LDS_BYTES, 32, 128, 0, 256},
+        {"w4_512x128F", conv_dma4w_kernel<4, 1, 32, false>, ConvDma4wCfg<4, 1, 32>::LDS_BYTES, 32, 128, 0, 256},
         {"persist1", conv_dmap_kernel<true>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
         {"persistF", conv_dmap_kernel<false>, ConvDmaPCfg::LDS_BYTES, 16, 128, 1},
         {"two80", conv_dma2_kernel<true>, ConvDma2Cfg::LDS_BYTES, 16, 128, 0, 256},
@@ -134,6 +139,7 @@ int main(int argc, char** argv) {
             || !strcmp(vars[v].name, "persist1") || !strcmp(vars[v].name, "t256x256");
 #else
             || (!strcmp(vars[v].name, "persist1") && sh.res) || (!strcmp(vars[v].name, "persistF") && !sh.res)
+            || (!strcmp(vars[v].name, "w4_256x256") && sh.res) || (!strcmp(vars[v].name, "w4_256x256F") && !sh.res) || (!strcmp(vars[v].name, "w4_512x128") && sh.res) || (!strcmp(vars[v].name, "w4_512x128F") && !sh.res)
             || (!strcmp(vars[v].name, "t256x128P") && sh.res) || (!strcmp(vars[v].name, "t256x256") && sh.res) || (!strcmp(vars[v].name, "t256x256F") && !sh.res);
 #endif
         for (int v = 0; v < NV; ++v) if (!skip[v]) hipLaunchKernelGGL(vars[v].kern, dim3(grid[v]), dim3(vars[v].threads), vars[v].lds, 0, aa[v]);
