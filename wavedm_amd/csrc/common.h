@@ -223,7 +223,6 @@ struct EnvCfg {
                           // in round 4, bit-identical to the launches, 3.6 % SLOWER end to end -- one workgroup per image reduces what 2 048 waves of gn_finalize do side by side)
     int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
-    int w4 = 0;           // WDM_W4=1: the 256 x 256 / 512 x 128 tiles of the 3x3 stride-1 convs on FOUR waves of 128 x 128 (conv_dma4w_kernel.h) instead of eight of 64 x 128 (same bits)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: the batched-GEMM form of the weight gradient everywhere, n images per group (0: direct kernel for 3x3 stride-1 layers, training)
 };
 const EnvCfg& env_cfg();

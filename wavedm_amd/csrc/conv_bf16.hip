@@ -4,7 +4,6 @@
 #include "conv_gemm_kernel.h"
 #include "conv_dma_kernel.h"
 #include "conv_dma256_kernel.h"
-#include "conv_dma4w_kernel.h"
 #include "conv_up4_kernel.h"
 #include "conv_dma8_kernel.h"
 #include "conv_s2_kernel.h"
