@@ -107,3 +107,20 @@ def test_loader_to_restore_pipeline(tmp_path):
         want, _, _ = O.restore(sd, cfg, small[k][0][:, :3], xT[k], 5, r=4)
         assert float((outs[k].cpu() - want).abs().max()) <= 1e-3
         assert abs(psnrs[k] - O.psnr_torch(small[k][0][:, 3:], want)) < 1e-2
+
+
+def test_writer_last_save_to_a_path_wins(tmp_path):
+    """Several encoder threads take the queue's FIFO order away: saves to the SAME path are ordered by sequence number -- whichever thread gets there
+    first, the file holds the LAST image saved to it."""
+    import numpy as np
+    from PIL import Image
+    from wavedm_amd.imageio import AsyncImageWriter
+    w = AsyncImageWriter(workers=8)
+    paths = [str(tmp_path / f"p{k}.png") for k in range(4)]
+    for rep in range(6):
+        for k, p in enumerate(paths):
+            img = torch.full((1, 3, 480, 720), (rep * 4 + k) / 255.0, device="cuda")
+            w.save(img, p)
+    w.close()
+    for k, p in enumerate(paths):
+        assert int(np.asarray(Image.open(p))[0, 0, 0]) == 5 * 4 + k

@@ -237,6 +237,7 @@ template <> struct TI<__bf16> {
         return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
     __device__ static __forceinline__ float raw16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+    __device__ static __forceinline__ void unpack2(unsigned u, float& lo, float& hi) { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
     __device__ static __forceinline__ float ld(const void* p, long long i) { return bf16_to_f32(((const bf16_raw*)p)[i]); }
     __device__ static __forceinline__ void st(void* p, long long i, float v) { ((bf16_raw*)p)[i] = f32_to_bf16(v); }
 };
@@ -263,6 +264,11 @@ template <> struct TI<f16_t> {
         return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
     __device__ static __forceinline__ float raw16_to_f32(unsigned short v) { return (float)__builtin_bit_cast(f16_t, v); }
+    __device__ static __forceinline__ void unpack2(unsigned u, float& lo, float& hi) {
+        typedef f16_t v2h __attribute__((ext_vector_type(2)));
+        const v2h h = __builtin_bit_cast(v2h, u);
+        lo = (float)h[0]; hi = (float)h[1];
+    }
     __device__ static __forceinline__ float ld(const void* p, long long i) { return (float)((const f16_t*)p)[i]; }
     __device__ static __forceinline__ void st(void* p, long long i, float v) { ((f16_t*)p)[i] = (f16_t)v; }
 };
@@ -687,7 +693,7 @@ __host__ __device__ __forceinline__ bool conv_epilogue_can_pack(const AT& a) {
 #ifdef WDM_NO_PACK          // tools: A/B against the fp32 form
     return false;
 #else
-    return a.res == nullptr && a.y_mode == Y_NHWC && (a.Cout % 8) == 0 && a.m_valid == 0;
+    return a.y_mode == Y_NHWC && (a.Cout % 8) == 0 && a.m_valid == 0 && !(a.up4 && a.res != nullptr);      // (round 5: a residual operand no longer forces the fp32 tile)
 #endif
 }
 constexpr int EPI_PACK_TILE = 64 * 128;      // LDS bytes per wave
@@ -703,6 +709,34 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
     const int ncol0 = n0 + (wave_n * WN + jp) * 16;            // first channel of this pass
     if (jp != 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }       // the previous pass's column reads (same wave: LDS in order)
     __builtin_amdgcn_sched_barrier(0);            // a pass's loads stay inside the pass (hoisted across passes they spill the accumulators of 256-column tiles)
+    // ---- residual operand (round 5): its rows come in like the output rows go out (a lane moves 16 bytes = 8 channels of a pixel, 8 rows per iteration) and are
+    // parked in the tile at the very place the final values of those outputs will sit, so that the accumulator-layout pass below finds the four residual values of
+    // a lane as ONE 8-byte read and puts alpha * acc + (bias + temb) + residual back in their place -- the same operations on the same numbers as conv_epilogue_w
+    // (fma, + residual, one rounding), hence the same bits, without the fp32 tile's three trips through LDS.
+    const bool has_res = a.res != nullptr;
+    if (has_res) {
+        constexpr unsigned OOBV = 0xFFFF0000u;
+        const long long out_rows = (long long)a.B * a.Hout * a.Wout;                   // (up4 / m_valid launches have no residual: conv_dispatch.inc)
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)(unsigned)(out_rows * a.res_s * 2), 0x00020000);
+        const int c8 = (lane & 7) * 8, lp = lane >> 3;
+        const int n = ncol0 + c8;
+        const unsigned vo_r = n < a.Cout ? (unsigned)((lp * a.res_s + n) * 2) : OOBV;
+        const int rd = lp * ROWB + (((lane & 7) ^ lp) << 4);
+        uint4 rv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mu = wave_m * EROWS + it * 8;                     // wave-uniform
+            const int img_u = mu / (TH * TW), rru = mu % (TH * TW);
+            const int oyu = oy0 + rru / TW, oxu = ox0 + rru % TW;
+            const int img_g = img0 + img_u;
+            const int so_pix = (img_g * a.Hout + oyu) * a.Wout + oxu;
+            rv[it] = img_g < a.B ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)vo_r, (int)((unsigned)so_pix * (unsigned)a.res_s * 2u), 0)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *(uint4*)(tp + rd + it * (8 * ROWB)) = (it & 1) ? make_uint4(rv[it].z, rv[it].w, rv[it].x, rv[it].y) : rv[it];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- final values in the accumulator layout -> bf16 tile
     {
         const int img_w = img0 + (wave_m * EROWS) / (TH * TW);
@@ -721,9 +755,16 @@ __device__ __forceinline__ void conv_epilogue_packed(const AT& a, f32x4 (&acc)[4
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = acc[i][jp + j];
+                float f0 = __builtin_fmaf(v[0], a.alpha, ad.x), f1 = __builtin_fmaf(v[1], a.alpha, ad.y), f2 = __builtin_fmaf(v[2], a.alpha, ad.z), f3 = __builtin_fmaf(v[3], a.alpha, ad.w);
+                if (has_res) {
+                    const uint2 rr = *(const uint2*)(tp + wr + i * (16 * ROWB));
+                    float r0, r1, r2, r3;
+                    TI<T>::unpack2(rr.x, r0, r1); TI<T>::unpack2(rr.y, r2, r3);
+                    f0 += r0; f1 += r1; f2 += r2; f3 += r3;
+                }
                 uint2 pk;
-                pk.x = TI<T>::pack2(__builtin_fmaf(v[0], a.alpha, ad.x), __builtin_fmaf(v[1], a.alpha, ad.y));
-                pk.y = TI<T>::pack2(__builtin_fmaf(v[2], a.alpha, ad.z), __builtin_fmaf(v[3], a.alpha, ad.w));
+                pk.x = TI<T>::pack2(f0, f1);
+                pk.y = TI<T>::pack2(f2, f3);
                 *(uint2*)(tp + wr + i * (16 * ROWB)) = pk;
             }
         }

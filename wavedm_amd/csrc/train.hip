@@ -734,7 +734,7 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
     int rc = WDM_OK;
     // 3x3 stride-1 layers on 16-pixel-wide maps, bf16: the direct kernel (conv_wgrad_kernel.h) -- no transposed copies, one launch + the partial reduction
     const bool map8 = H == 8 && W == 8;
-    const bool fits32 = (unsigned long long)c.B * H * W * (unsigned long long)std::max(std::max(cout, s0->xs), s1 ? s1->xs : 0) * 2ull < (1ull << 32);      // buffer offsets are 32-bit
+    const bool fits32 = (unsigned long long)c.B * H * W * (unsigned long long)std::max(std::max(cout, s0->xs), s1 ? s1->xs : 0) * 2ull < 4294901760ull;      // buffer offsets are 32-bit, 0xFFFF0000 marks "outside" (conv_dispatch.inc: set_extents)
     if (shifted && fits32 && c.dtype == WDM_BF16 && env_cfg().wgrad_bg == 0 && ((W % 16 == 0 && H % 8 == 0) || map8) && dy.xs == cout && cout % 8 == 0 && s0->xs % 8 == 0 &&
         (!s1 || (s0->C % 64 == 0 && s1->xs % 8 == 0)) && cin % 8 == 0) {
         WgradArgs w{};
@@ -752,14 +752,14 @@ int conv_wgrad(Ctx& c, int mode, const Tens& x0, const Tens* x1, const Tens& dy,
         float* part = (float*)c.ar->alloc((size_t)9 * w.S * rows_g * cin * sizeof(float));
         if (!part) WDM_FAIL(WDM_ENOMEM, "workspace too small (wgrad partials)");
         w.part = part;
+        if (db || dtemb) {          // (allocations outside the dry test: a sizing pass must see the same arena sequence as the real one)
+            float* per_img = dtemb; int ld = dtemb_ld;
+            if (!per_img) { per_img = (float*)c.ar->alloc((size_t)c.B * cout * sizeof(float)); ld = cout; if (!per_img) WDM_FAIL(WDM_ENOMEM, "workspace too small (bias gradient)"); }
+            WDM_TRY(colsum(c, dy, per_img, true, false, ld));
+            if (db && !c.dry) hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64, 1), dim3(256), 0, c.s, per_img, ld, cout, c.B, 1, db, cout, 0);
+            if (!dtemb) c.ar->free(per_img);
+        }
         if (!c.dry) {
-            if (db || dtemb) {
-                float* per_img = dtemb; int ld = dtemb_ld;
-                if (!per_img) { per_img = (float*)c.ar->alloc((size_t)c.B * cout * sizeof(float)); ld = cout; if (!per_img) WDM_FAIL(WDM_ENOMEM, "workspace too small (bias gradient)"); }
-                WDM_TRY(colsum(c, dy, per_img, true, false, ld));
-                if (db) hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64, 1), dim3(256), 0, c.s, per_img, ld, cout, c.B, 1, db, cout, 0);
-                if (!dtemb) c.ar->free(per_img);
-            }
             {   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: once per (kernel, device)
                 static std::atomic<unsigned> devs{0};
                 int dev = 0;

@@ -261,11 +261,15 @@ int wdm_unet::forward(Ctx& c, const void* x96, const float* t, int n_t, float* e
     }
     // arrival counters of the launches that finalise their consumer's GroupNorm themselves (gn_arrive.h; ~17 of them per call): one slot of B ints each, zeroed here
     // (a last arriver resets its counter, but the arena hands out whatever the previous call left at these addresses)
+    // Only with WDM_GN_INLINE=2 (opt-in, slower: gn_arrive.h): the default path neither allocates nor zeroes them -- one launch fewer on the serial chain; the dry
+    // sizing run follows the same switch (a refresh of the switches invalidates workspace sizes anyway: blocks.hip).
     constexpr int FIN_SLOTS = 48;
-    c.fin_cap = FIN_SLOTS; c.fin_used = 0;
-    c.fin_cnt = (int*)c.ar->alloc((size_t)FIN_SLOTS * c.B * sizeof(int));
-    if (!c.fin_cnt) WDM_FAIL(WDM_ENOMEM, "workspace too small (arrival counters)");
-    if (!c.dry) WDM_HIP(hipMemsetAsync(c.fin_cnt, 0, (size_t)FIN_SLOTS * c.B * sizeof(int), c.s));
+    c.fin_cap = FIN_SLOTS; c.fin_used = 0; c.fin_cnt = nullptr;
+    if (env_cfg().gn_inline >= 2) {
+        c.fin_cnt = (int*)c.ar->alloc((size_t)FIN_SLOTS * c.B * sizeof(int));
+        if (!c.fin_cnt) WDM_FAIL(WDM_ENOMEM, "workspace too small (arrival counters)");
+        if (!c.dry) WDM_HIP(hipMemsetAsync(c.fin_cnt, 0, (size_t)FIN_SLOTS * c.B * sizeof(int), c.s));
+    }
     // the norm a tensor meets next, for the producer to finalise (run_conv: fin) -- only where wants_fin says the consumer would otherwise launch gn_finalize
     NormW fn;
     FinReq fr{&fn, nullptr, 1};

@@ -133,7 +133,11 @@ class DenoisingDiffusion_Wavelet(object):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and os.environ.get("WAVEDM_GRAD_BUCKETS", "8") != "0":
             # ... and its bucketed gradient all-reduce that overlaps the backward (Trainer.allreduce_grads_overlapped); WAVEDM_GRAD_BUCKETS=0: one flat all-reduce
-            tr.enable_grad_buckets(int(os.environ.get("WAVEDM_GRAD_BUCKETS", "8")))
+            try:
+                nb = int(os.environ.get("WAVEDM_GRAD_BUCKETS", "8"))
+            except ValueError:
+                nb = 8                                                          # a malformed value must not take every rank down at start-up
+            tr.enable_grad_buckets(nb)                                          # (clamped to [0, 64] there; bucket bounds depend on the model alone: equal on every rank)
         self.trainer = tr
         return tr
 

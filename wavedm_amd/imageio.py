@@ -74,7 +74,9 @@ def psnr_from_sums(sums, H, W):
 class AsyncImageWriter:
     """PNG output off the critical path: 8-bit conversion on the device, D2H copy on a side stream into pinned memory, encoding in worker threads.
     `workers` threads share one queue (zlib releases the GIL): with one thread the seven PNGs per 480x720 image of restore() took 3 s of an 8-image call
-    whose sampling takes 1.5 s (bench.py: configs[4] whole pipeline); files are PIL's default encoding, as torchvision.utils.save_image writes them."""
+    whose sampling takes 1.5 s (bench.py: configs[4] whole pipeline); files are PIL's default encoding, as torchvision.utils.save_image writes them.
+    Several threads take the FIFO order away, so saves to the SAME path are ordered explicitly: every save gets a per-path sequence number, a worker holds the path's
+    lock while it writes and skips its item when a later save to that path has been queued -- the last save wins, as with one thread."""
 
     def __init__(self, max_pending: int = 64, workers: int = 0):
         self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
@@ -82,6 +84,8 @@ class AsyncImageWriter:
         self._threads = [threading.Thread(target=self._run, name=f"wavedm-png-writer-{k}", daemon=True) for k in range(n)]
         self._stream = None
         self._errors = []
+        self._seq = {}                                  # path -> (sequence number of the latest save queued, lock held while a worker writes the file)
+        self._seq_mu = threading.Lock()
         for t in self._threads:
             t.start()
 
@@ -92,11 +96,17 @@ class AsyncImageWriter:
             try:
                 if item is None:
                     return
-                host, event, path = item
+                host, event, path, seq = item
                 event.synchronize()
                 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
                 arr = host.numpy()
-                Image.fromarray(arr[..., 0] if arr.shape[-1] == 1 else arr).save(path)
+                with self._seq_mu:
+                    lock = self._seq[path][1]
+                with lock:
+                    with self._seq_mu:
+                        latest = self._seq[path][0]
+                    if seq == latest:                       # (an older save to a path that has been saved again since: the newer one stands)
+                        Image.fromarray(arr[..., 0] if arr.shape[-1] == 1 else arr).save(path)
             except Exception as e:                      # surfaced by flush()
                 self._errors.append(e)
             finally:
@@ -118,10 +128,15 @@ class AsyncImageWriter:
             ev = torch.cuda.Event()
             ev.record(self._stream)
         u8.record_stream(self._stream)
-        self._q.put((host, ev, path))
+        with self._seq_mu:
+            n, lock = self._seq.get(path, (0, None))
+            self._seq[path] = (n + 1, lock or threading.Lock())
+        self._q.put((host, ev, path, n + 1))
 
     def flush(self):
         self._q.join()
+        with self._seq_mu:
+            self._seq.clear()
         if self._errors:
             e, self._errors = self._errors[0], []
             raise e

@@ -52,6 +52,7 @@ class Trainer:
             _lib.check(L.wdm_trainer_param_info(t, i, C.byref(name), C.byref(ndim), C.byref(shape), C.byref(off)))
             self.layout[name.value.decode()] = (int(off.value), tuple(int(shape[k]) for k in range(ndim.value)))
         n = int(L.wdm_trainer_num_floats(t))
+        self._n_floats = n
         with torch.cuda.device(self.device):
             self.params = torch.zeros(n, device=self.device)
             self.grads = torch.zeros(n, device=self.device)
@@ -122,7 +123,10 @@ class Trainer:
         with torch.cuda.device(self.device):
             # workspace = every saved activation + its gradient + operand transposes of the largest layer.  It is sized from the batch
             # (288 GB of HBM: generosity is cheap) and doubled on demand: the library reports exhaustion as an error, never overruns.
-            need = B * 96 * R * R * 4 * 160 + (1 << 28)
+            # ... plus the forward AND dgrad weight layouts of every conv, packed at the start of the step and kept for its whole length (train_unet.hip: pack_region):
+            # about twice the parameter bytes in the model dtype -- without this term small batches took the double-and-retry path on every first step
+            dsize = 2 if self._dtype_code == _lib.WDM_BF16 else 4
+            need = B * 96 * R * R * 4 * 160 + 2 * self._n_floats * dsize + (1 << 28)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -150,8 +154,9 @@ class Trainer:
     def enable_grad_buckets(self, n: int = 8):
         """The next loss_and_grads calls record an event behind the last launch that writes each of (at most) n buckets of the flat gradient buffer --
         it fills from its end while the backward runs -- so that allreduce_grads_overlapped can start a bucket's all-reduce before the backward is over.
-        n = 0 switches it off."""
+        n = 0 switches it off; n is clamped to the C API's limit of 64 buckets."""
         import ctypes as C
+        n = max(0, min(64, int(n)))
         with torch.cuda.device(self.device):
             self._gev = [torch.cuda.Event() for _ in range(int(n))]
             for ev in self._gev:
