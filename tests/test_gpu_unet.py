@@ -472,3 +472,33 @@ def test_f16_weight_outside_the_fp16_range_is_refused():
     good.load_state_dict(sd, strict=True)
     good.cuda().pack_weights()
     assert torch.isfinite(good(seeded((1, 96, 16, 16), 3).cuda(), torch.tensor([10.0]))).all()
+
+
+def test_sampling_loop_replayed_from_a_hipgraph_gives_the_same_bits():
+    """WAVEDM_GRAPH=1 (opt-in): the whole DDIM loop captured once and replayed -- independent crops and a stitched patch list, first call (capture) and second call
+    (replay with other inputs): bit-identical to direct launches."""
+    from wavedm_amd import procedural as P
+    from wavedm_amd import sampling
+    from oracle import wavedm_oracle as O
+    d, _ = make_diffusion(P.reduced_config(), "bf16", 6)
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["WAVEDM_GRAPH"] = mode
+        try:
+            res = []
+            for seed in (3, 4):                                   # second seed: same shapes, other inputs -> the cached graph is replayed
+                rainy, x_T = P.synthetic_batch(5, patch_px=64, seed=seed)
+                res.append(d.restore_batch(rainy.cuda(), x_T.cuda()))
+                g = torch.Generator().manual_seed(seed)
+                img, xT = torch.rand(1, 3, 120, 180, generator=g).cuda(), torch.randn(1, 3, 30, 45, generator=g).cuda()
+                xc = d.wavelet_dec(2 * img - 1)
+                xs, x0 = d.sample_image(xc, xT, x_other=xc[:, 3:].contiguous(), last=False, patch_locs=O.grid_corners(30, 45, 16, 4), patch_size=16, use_other=True)
+                res.append((xs[-1], x0[-5], x0[0]))
+            outs[mode] = res
+        finally:
+            os.environ.pop("WAVEDM_GRAPH", None)
+    assert sampling._GRAPHS is not None and len(sampling._GRAPHS) == 2
+    for a, b in zip(outs["0"], outs["1"]):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    sampling.graph_cache_clear()

@@ -24,7 +24,20 @@ int main() {
         for (int i = 0; i < it; ++i) hipLaunchKernelGGL(empty_kernel, dim3(c[0]), dim3(c[1]), c[2] * 1024, 0, a);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("grid %5d x %3d threads, LDS %3d KB, store %d : %6.2f us per launch\n", c[0], c[1], c[2], c[3], ms / it * 1e3);
+        // the same 200 launches as ONE hipGraph (stream capture): does the replayed graph shorten the boundary between dependent kernels?
+        hipStream_t st; CK(hipStreamCreate(&st));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < it; ++i) hipLaunchKernelGGL(empty_kernel, dim3(c[0]), dim3(c[1]), c[2] * 1024, st, a);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float msg; CK(hipEventElapsedTime(&msg, e0, e1));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(st));
+        printf("grid %5d x %3d threads, LDS %3d KB, store %d : %6.2f us per launch, %6.2f as a graph\n", c[0], c[1], c[2], c[3], ms / it * 1e3, msg / it * 1e3);
     }
     return 0;
 }

@@ -356,7 +356,7 @@ class DenoisingDiffusion_Wavelet(object):
         skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
         seq = list(range(0, self.config.diffusion.num_diffusion_timesteps, skip))
         xs, x0_preds = sampling.ddim_sample(self.model, x_T, x_cond, x_other, seq, self.betas, corners=None,
-                                            max_batch=getattr(self.args, "max_batch", 64),
+                                            max_batch=getattr(self.args, "max_batch", 64), keep={keep, -1},     # x0_preds[keep], xs[-1] (xs[keep] after an early stop)
                                             stop_at=keep if early_stop else None)      # early_stop: skip the discarded tail
         pc = self.config.model.pred_channels
         x0 = x0_preds[keep]

@@ -65,6 +65,64 @@ def _chunk_streams(dev, n):
     return [torch.cuda.Stream(device=dev) for _ in range(n)]
 
 
+# ---- the whole sampling loop as ONE hipGraph (OPT-IN: WAVEDM_GRAPH=1) -----------------------------------------------------------------------------------
+# Back-to-back launches of an EMPTY kernel cost 3.4 ... 3.6 us each on a stream and 1.6 us replayed from a hipGraph (tools/launch_ubench.hip, round 5) -- which
+# suggested ~4 % for the ~10 000 launches of a trajectory.  Built and measured (scripts/graph_probe.py, 64 crops x 20 steps, one process): 103.9 / 104.0 ms
+# direct, 104.0 / 103.8 ms replayed -- nothing.  The 3.5 us was the HOST's submission rate, which real kernels (15 ... 200 us each) hide completely; the device-side
+# boundary is the same either way.  What the graph does buy is a free host thread during sampling and launch-latency immunity at tiny batches, so it stays as
+# an option: the loop is a fixed launch sequence for given shapes (no host decision depends on device data), captured once per (model buffers, shapes, timestep
+# sequence, patch list) and replayed; inputs are copied into the graph's static tensors, kept results cloned out of its memory.  Same kernels, same arguments,
+# same order: the same bits (tests/test_gpu_unet.py).  Profiling with per-launch events, several streams and the patch-sharded mode always launch directly.
+_GRAPHS = None
+_GRAPH_CACHE = int(os.environ.get("WAVEDM_GRAPH_CACHE", "6"))        # captured loops kept (least recently used first out): each holds its activations' memory pool
+
+
+def _replay_graph(unet, run_loop, x, x_cond, x_other, n_run, key_tail):
+    global _GRAPHS
+    from collections import OrderedDict
+    if _GRAPHS is None:
+        _GRAPHS = OrderedDict()
+    dev = x.device
+    packed = unet.pack_weights()
+    key = (id(unet), packed.data_ptr(), unet._dtype_code, _lib.env_generation(), str(dev), tuple(x.shape), tuple(x_cond.shape),
+           None if x_other is None else tuple(x_other.shape)) + tuple(key_tail)
+    ent = _GRAPHS.get(key)
+    if ent is None:
+        xs_, xc_, xo_ = x.clone(), x_cond.clone(), (None if x_other is None else x_other.clone())
+        # one step directly, on a side stream, before the capture: first-use initialisation (hipFuncSetAttribute per kernel, workspace and switch set-up) is not capturable
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run_loop(xs_, xc_, xo_, 1, False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (other threads -- the PNG writer's -- keep using the device meanwhile)
+            out_xs, out_x0 = run_loop(xs_, xc_, xo_, n_run, False)
+        # the entry keeps alive what the captured launches point at: the packed weights and the workspace of this moment (the model may replace either later)
+        # ... and, through the loop's closure, the patch list and the timestep tensor of THIS call (a later call's are other tensors)
+        ent = (g, xs_, xc_, xo_, out_xs, out_x0, packed, dict(unet._ws), run_loop)
+        _GRAPHS[key] = ent
+        while len(_GRAPHS) > max(1, _GRAPH_CACHE):
+            _GRAPHS.popitem(last=False)
+    else:
+        _GRAPHS.move_to_end(key)
+        g, xs_, xc_, xo_, out_xs, out_x0 = ent[:6]
+        xs_.copy_(x)
+        xc_.copy_(x_cond)
+        if xo_ is not None:
+            xo_.copy_(x_other)
+    g.replay()
+    xs = [x] + [None if t is None else t.clone() for t in out_xs[1:]]          # out of the graph's memory: the next replay overwrites it
+    x0_preds = [None if t is None else t.clone() for t in out_x0]
+    return xs, x0_preds
+
+
+def graph_cache_clear():
+    """Drop every captured sampling loop (and the memory its activations live in)."""
+    global _GRAPHS
+    _GRAPHS = None
+
+
 def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None,
                 patch_group=None, streams=None):
     """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
@@ -132,88 +190,102 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         sharded = corners is not None and patch_group is not None
         if patch_group is not None and corners is None:
             raise ValueError("patch_group needs a corner list: independent crops shard by image (parallel.restore_sharded)")
-        st = _lib.stream_ptr()
-        x96 = torch.empty(max(n, 1), p, p, cin, device=dev, dtype=unet._torch_dtype)
-        if n:
-            _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
-            if nother:
-                _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
-        eps = torch.empty(max(n, 1), pc, p, p, device=dev, dtype=torch.float32)
-        acc_cnt = torch.empty(2 * x.numel(), device=dev, dtype=torch.float32) if sharded else None
-
         seq = list(seq)
         seq_next = [-1] + seq[:-1]
         abar = alpha_bar_table(betas)
         t_dev = torch.tensor([float(v) for v in reversed(seq)], dtype=torch.float32).to(dev)
-        # the timestep-dependent part of the UNet (embedding MLP, every temb_proj) for the WHOLE sequence at once: four launches per run instead of per step
-        temb = unet.temb_table(t_dev, B=min(max(n, 1), max_batch)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
-        xs, x0_preds = [x], []
-        xt = x
-        # chunks of independent crops, one HIP stream each (see `streams`)
-        chunks = None
-        ns = int(os.environ.get("WAVEDM_STREAMS", "1")) if streams is None else int(streams)
-        if corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on():
-            per = -(-n // ns)
-            main = torch.cuda.current_stream()
-            chunks = []
-            pool = _chunk_streams(dev, ns)
-            for ci, lo in enumerate(range(0, n, per)):
-                sc = pool[ci]
-                sc.wait_stream(main)                                  # inputs, x96's constant channels and the temb table are ready
-                chunks.append((lo, min(lo + per, n), sc))
-            for ci, (lo, hi, _) in enumerate(chunks):                # the chunks' workspaces, allocated HERE, on the caller's stream, each for the largest
-                unet.workspace(min(max_batch, hi - lo), dev, ci)     # call its slot will run (smaller calls reuse it: DiffusionUNet.workspace)
         n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
         assert 1 <= n_run <= len(seq), f"stop_at={stop_at} out of range for {len(seq)} steps"
-        if chunks is not None:
-            _lib.set_concurrent_streams(len(chunks))                  # tile rules that count one launch's workgroups count the chunks' together (whole loop)
-        try:
-            for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
-                if k >= n_run:
-                    x0_preds.append(None)
-                    xs.append(None)
-                    continue
-                at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
-                s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
-                san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
-                x0 = torch.empty_like(x)
-                xn = torch.empty_like(x)
-                if chunks is not None:
-                    # independent crops: every chunk's step on its own stream (same kernels, same per-image bits)
-                    for ci, (lo, hi, sc) in enumerate(chunks):
-                        with torch.cuda.stream(sc):
-                            stc = sc.cuda_stream
-                            _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt[lo:hi]), pc, H, W, None, hi - lo, p, _lib.ptr(x96[lo:hi]), cin, ncond, unet._dtype_code, stc))
-                            for i in range(lo, hi, max_batch):
-                                j = min(i + max_batch, hi)
-                                unet.forward_nhwc(x96[i:j], t_dev[k:k + 1], eps[i:j], temb_row=None if temb is None else temb[k], ws_slot=ci)
-                            _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps[lo:hi]), None, hi - lo, p, _lib.ptr(xt[lo:hi]), hi - lo, H, W, s1m, sa, san, c2,
-                                                         _lib.ptr(x0[lo:hi]), _lib.ptr(xn[lo:hi]), stc))
-                    x0_preds.append(x0)
-                    xs.append(xn)
-                    xt = xn
-                    continue
-                if n:
-                    _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
-                for i in range(0, n, max_batch):
-                    unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
-                if sharded:
-                    _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
-                    dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
-                    _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
-                else:
-                    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
-                                                 _lib.ptr(x0), _lib.ptr(xn), st))
-                x0_preds.append(x0)
-                xs.append(xn)
-                xt = xn
-        finally:
+        keep_set = None if keep == "all" else frozenset(int(v) for v in keep)
+        ns = int(os.environ.get("WAVEDM_STREAMS", "1")) if streams is None else int(streams)
+        multi = corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on()
+
+        def run_loop(x, x_cond, x_other, n_steps, use_chunks):
+            """The sampling loop proper: every launch goes to the CURRENT stream (or the chunks' streams) -- also the body a hipGraph is captured from."""
+            st = _lib.stream_ptr()
+            x96 = torch.empty(max(n, 1), p, p, cin, device=dev, dtype=unet._torch_dtype)
+            if n:
+                _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_cond), ncond, H, W, pptr, n, p, _lib.ptr(x96), cin, 0, unet._dtype_code, st))
+                if nother:
+                    _lib.check(L.wdm_pack_channels(h, _lib.ptr(x_other), nother, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond + pc, unet._dtype_code, st))
+            eps = torch.empty(max(n, 1), pc, p, p, device=dev, dtype=torch.float32)
+            acc_cnt = torch.empty(2 * x.numel(), device=dev, dtype=torch.float32) if sharded else None
+            # the timestep-dependent part of the UNet (embedding MLP, every temb_proj) for the WHOLE sequence at once: four launches per run instead of per step
+            temb = unet.temb_table(t_dev, B=min(max(n, 1), max_batch)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
+            S = len(seq)
+            xs, x0_preds = [x], []
+            xt = x
+            # chunks of independent crops, one HIP stream each (see `streams`)
+            chunks = None
+            if use_chunks:
+                per = -(-n // ns)
+                main = torch.cuda.current_stream()
+                chunks = []
+                pool = _chunk_streams(dev, ns)
+                for ci, lo in enumerate(range(0, n, per)):
+                    sc = pool[ci]
+                    sc.wait_stream(main)                                  # inputs, x96's constant channels and the temb table are ready
+                    chunks.append((lo, min(lo + per, n), sc))
+                for ci, (lo, hi, _) in enumerate(chunks):                # the chunks' workspaces, allocated HERE, on the caller's stream, each for the largest
+                    unet.workspace(min(max_batch, hi - lo), dev, ci)     # call its slot will run (smaller calls reuse it: DiffusionUNet.workspace)
             if chunks is not None:
-                # also on an exception: x96, eps, xn and the temb table are released on the caller's stream, which must not happen while a side
-                # stream's kernels may still touch them
-                _lib.set_concurrent_streams(1)
-                for (_, _, sc) in chunks:
-                    torch.cuda.current_stream().wait_stream(sc)        # the caller's stream sees every chunk's results
+                _lib.set_concurrent_streams(len(chunks))                  # tile rules that count one launch's workgroups count the chunks' together (whole loop)
+            try:
+                for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
+                    if k >= n_steps:
+                        x0_preds.append(None)
+                        xs.append(None)
+                        continue
+                    at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
+                    s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
+                    san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
+                    x0 = torch.empty_like(x)
+                    xn = torch.empty_like(x)
+                    if chunks is not None:
+                        # independent crops: every chunk's step on its own stream (same kernels, same per-image bits)
+                        for ci, (lo, hi, sc) in enumerate(chunks):
+                            with torch.cuda.stream(sc):
+                                stc = sc.cuda_stream
+                                _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt[lo:hi]), pc, H, W, None, hi - lo, p, _lib.ptr(x96[lo:hi]), cin, ncond, unet._dtype_code, stc))
+                                for i in range(lo, hi, max_batch):
+                                    j = min(i + max_batch, hi)
+                                    unet.forward_nhwc(x96[i:j], t_dev[k:k + 1], eps[i:j], temb_row=None if temb is None else temb[k], ws_slot=ci)
+                                _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps[lo:hi]), None, hi - lo, p, _lib.ptr(xt[lo:hi]), hi - lo, H, W, s1m, sa, san, c2,
+                                                             _lib.ptr(x0[lo:hi]), _lib.ptr(xn[lo:hi]), stc))
+                    else:
+                        if n:
+                            _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
+                        for i in range(0, n, max_batch):
+                            unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
+                        if sharded:
+                            _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
+                            dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
+                            _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
+                        else:
+                            _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
+                                                         _lib.ptr(x0), _lib.ptr(xn), st))
+                    # lists as the reference returns them; with `keep` given, what nobody asked for is dropped at once (inside a captured graph its memory is reused)
+                    x0_preds.append(x0 if keep_set is None or (k - S) in keep_set else None)
+                    xs.append(xn)
+                    if keep_set is not None and len(xs) >= 3:
+                        xs[-2] = xs[-2] if (len(xs) - 2 - (S + 1)) in keep_set else None
+                    xt = xn
+            finally:
+                if chunks is not None:
+                    # also on an exception: x96, eps, xn and the temb table are released on the caller's stream, which must not happen while a side
+                    # stream's kernels may still touch them
+                    _lib.set_concurrent_streams(1)
+                    for (_, _, sc) in chunks:
+                        torch.cuda.current_stream().wait_stream(sc)        # the caller's stream sees every chunk's results
+            return xs, x0_preds
+
+        graphed = (os.environ.get("WAVEDM_GRAPH", "0") == "1" and not sharded and not multi and n > 0 and not _lib.prof_on() and
+                   not torch.cuda.is_current_stream_capturing())
+        if graphed:
+            xs, x0_preds = _replay_graph(unet, run_loop, x, x_cond, x_other, n_run,
+                                         (tuple(seq), None if corners is None else tuple(map(tuple, tri)), p, max_batch, keep_set, n_run, betas.detach().float().cpu().numpy().tobytes()))
+        else:
+            xs, x0_preds = run_loop(x, x_cond, x_other, n_run, multi)
         if keep != "all":
             S = len(x0_preds)
             x0_preds = [t if (i - S) in keep else None for i, t in enumerate(x0_preds)]
