@@ -234,7 +234,7 @@ def main():
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
         traffic, traffic_src = None, None
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", f"{tag}_traffic.json")))
                 traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
@@ -313,14 +313,25 @@ def main():
         import contextlib, io
         extras = []
 
-        def timed(fn, n_warm=1):
+        last_runs = []
+
+        def timed(fn, n_warm=1, passes=3):
+            """median of `passes` timed passes after the warm-up; the individual times stay in last_runs (no single-pass figures)"""
             for _ in range(n_warm):
                 fn()
-            torch.cuda.synchronize()
-            tq = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            return time.perf_counter() - tq
+            runs = []
+            for _ in range(passes):
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                runs.append(time.perf_counter() - tq)
+            last_runs[:] = runs
+            return sorted(runs)[len(runs) // 2]
+
+        def spread():
+            return {"passes": len(last_runs), "ms_min": round(min(last_runs) * 1e3, 1), "ms_median": round(sorted(last_runs)[len(last_runs) // 2] * 1e3, 1),
+                    "ms_max": round(max(last_runs) * 1e3, 1)}
 
         def conv_flops_per_pass(fn):
             _lib.prof_enable(True)
@@ -342,11 +353,12 @@ def main():
             with contextlib.redirect_stdout(io.StringIO()):
                 rest4.restore(loader4, validation="raindrop", r=16)
         t4 = timed(pass_c4)
+        sp4 = spread()
         a4.sampling_timesteps = 5
         fl4 = conv_flops_per_pass(pass_c4) * 10
         extras.append({"workload": "BASELINE.json configs[4] per GPU: 8 whole 480x720 images, 45 stitched 64x64 patches each (r = 16), 50 DDIM steps, "
                                    "8 images per sampler call", "value": round(8 / t4, 3), "unit": "img/s", "ms_per_step": round(t4 * 1e3, 1),
-                       "steps": 1, "warmup": 1, "conv_tflops": round(fl4 / t4 / 1e12, 1)})
+                       "steps": 3, "warmup": 1, "spread": sp4, "conv_tflops": round(fl4 / t4 / 1e12, 1)})
         d.args = a
         log(f"[bench] extra configs[4]: {8 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per 8 images)")
         del rest4, loader4
@@ -389,7 +401,7 @@ def main():
             extras.append({"workload": "BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: 8 PNG pairs on disk -> RainDrop loader (PIL, 4 workers) -> device HFRM "
                                        "(procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, 50 DDIM steps, 8 images per sampler call -> "
                                        "IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
-                           "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 1, "warmup": 1, "pngs_written": n_png,
+                           "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 3, "warmup": 1, "spread": spread(), "pngs_written": n_png,
                            "vs_identity_standin_leg": round(t4 / t5, 3)})
             log(f"[bench] extra configs[4] whole pipeline (real HFRM, loader, PNGs): {8 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per 8 images, {n_png} PNGs)")
             rest5.writer.close()
@@ -414,10 +426,11 @@ def main():
         d2.restore_batch(r2, x2)                                            # warm-up: 10 steps of the same shapes (first-use costs, clocks)
         a2.sampling_timesteps = 100
         t2 = timed(lambda: d2.restore_batch(r2, x2), n_warm=0)
+        sp2 = spread()
         a2.sampling_timesteps = 5
         fl2 = conv_flops_per_pass(lambda: d2.restore_batch(r2, x2)) * 20
         extras.append({"workload": "BASELINE.json configs[2]: 256 patches of 128x128 (512x512 px crops), 100 DDIM steps", "value": round(256 / t2, 3),
-                       "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 1, "warmup": "10 DDIM steps of the same batch", "conv_tflops": round(fl2 / t2 / 1e12, 1)})
+                       "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 3, "warmup": "10 DDIM steps of the same batch", "spread": sp2, "conv_tflops": round(fl2 / t2 / 1e12, 1)})
         log(f"[bench] extra configs[2]: {256 / t2:.2f} img/s ({t2:.2f} s per 256 patches)")
         del d2, r2, x2
         torch.cuda.empty_cache()
