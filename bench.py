@@ -229,7 +229,8 @@ def main():
             log(f"[shape] {e['kernel']:<64s} n {e['launches']:5d}  avg {e['ms'] / e['launches'] * 1e3:8.1f} us  {e['flops'] / e['ms'] / 1e9:7.1f} TFLOP/s  "
                 f"{100 * e['ms'] / tot_ms:5.1f}%")
         dom = rep[0]
-        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "f16") else MFMA_F32_PEAK_TFLOPS
+        # f32x3: one fp32 product = four MFMA-units of bf16 work (two K = 32 bf16 MFMAs per 16 channels): 2500 / 4
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "f16") else MFMA_BF16_PEAK_TFLOPS / 4 if args.dtype == "f32x3" else MFMA_F32_PEAK_TFLOPS
         ach = dom["flops"] / dom["ms"] / 1e9
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
