@@ -219,3 +219,19 @@ def test_patch_gather_scatter_ddim(gu, O):
     _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps_d), _lib.ptr(pt2), 1, p, _lib.ptr(xt_d), 1, H, W, 0.5, 0.5, 0.5, 0.5,
                                  _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
     assert torch.isnan(x0.cpu()[0, 0, H - 1, W - 1]) and not torch.isnan(x0.cpu()[0, 0, 0, 0])
+
+
+def test_f16_saturates_instead_of_overflowing(gu):
+    """The f16 mode's kernels set MODE.FP16_OVFL: a conv output (or a layout conversion) beyond the fp16 range comes out as +-65504, not +-inf -- an out-of-range activation
+    cannot turn the rest of a trajectory into NaNs.  (Weights out of range are refused at load time: test_f16_weight_outside_the_fp16_range_is_refused.)"""
+    w = gu.seeded((128, 64, 3, 3), 1)
+    b = gu.seeded((128,), 2)
+    x = gu.seeded((1, 64, 16, 16), 3) * 3.0e3                    # |y| ~ 3e3 * sqrt(576) ~ 7e4: beyond 65504 in many places
+    y = gu.conv(w, b, 0, x, "f16")
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    assert float(ref.abs().max()) > 7.0e4
+    assert torch.isfinite(y).all() and float(y.abs().max()) == 65504.0
+    inside = ref.abs() < 6.0e4
+    assert float((y - ref)[inside].abs().max() / ref[inside].abs().max()) <= 2e-3      # what lies inside the range is the ordinary f16 result
+    big = gu.seeded((1, 64, 16, 16), 4) * 1.0e5                  # the input conversion saturates as well
+    assert torch.isfinite(gu.conv(w * 1e-6, b, 0, big, "f16")).all()

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     using T = T_;
     constexpr int N = C::N, QB = C::QB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16_mode_init<T>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // The four query blocks of an image run on the SAME XCD (block id % 8, used for speed only), back to back: the image's K and V^T are

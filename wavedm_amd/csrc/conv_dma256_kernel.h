@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
     using T = T_;
     constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16_mode_init<T>();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -54,6 +54,7 @@ __global__ __launch_bounds__((ConvDma8Cfg<BN_, NI_>::NTHREADS), 2) void conv_dma
     using T = T_;
     constexpr int ACP = C::A_CPW, BCP = C::B_CPW, TH = C::TH, TW = C::TW, NI = C::NI, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16_mode_init<T>();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

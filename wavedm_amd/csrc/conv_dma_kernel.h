@@ -67,6 +67,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     using T = T_;                      // __bf16 or f16_t: same layouts, same instruction counts
     constexpr int TH = C::TH, TW = C::TW, WM = C::WM, WN = C::WN, BN = C::BN, RS = C::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16_mode_init<T>();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

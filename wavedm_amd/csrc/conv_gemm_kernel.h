@@ -50,6 +50,7 @@ template <int TH, int TW, int NI, int WAVES_M, int WAVES_N, int WM, int WN, type
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bid, char* smem) {
     using C = GemmCfg<TH, TW, NI, WAVES_M, WAVES_N, WM, WN>;
     using T = T_;
+    h16_mode_init<T>();
     constexpr int BN = C::BN, A_BYTES = C::A_BYTES, STAGE = C::STAGE, A_CPW = C::A_CPW, B_CPW = C::B_CPW;
 
     const int tid = threadIdx.x;

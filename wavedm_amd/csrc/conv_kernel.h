@@ -273,6 +273,13 @@ template <> struct TI<f16_t> {
     __device__ static __forceinline__ void st(void* p, long long i, float v) { ((f16_t*)p)[i] = (f16_t)v; }
 };
 
+// Range of the f16 mode: every kernel that packs fp16 sets MODE.FP16_OVFL at its start -- an overflowing conversion then gives +-65504 instead of +-inf (true
+// infinities and NaNs pass: measured on gfx950, tools: v_cvt_pk_f16_f32 of 7e4 -> 0x7bff with the bit, 0x7c00 without).  An activation beyond the fp16 range
+// (none occurs in this architecture: GroupNorm bounds every conv input) saturates instead of turning the rest of the trajectory into NaNs; weights outside the
+// range are refused when they are loaded (wdm_unet_load_param).  One scalar instruction per kernel; nothing for the other element types.
+template <typename T> __device__ __forceinline__ void h16_mode_init() {}
+template <> __device__ __forceinline__ void h16_mode_init<f16_t>() { __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1); }      // hwreg(HW_REG_MODE, 23, 1) <- 1
+
 __device__ __forceinline__ float silu_f(float v) {
     // x * sigmoid(x) = x / (1 + e^-x)   (unet.py:31-33); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE divide:
     // this runs once per staged element in the conv prologue, where VALU issue slots compete with the MFMA stream
@@ -934,6 +941,7 @@ __global__ __launch_bounds__((ConvCfg<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM,
     constexpr int NDX = (MODE == MODE_S1 || MODE == MODE_S2) ? 3 : 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16_mode_init<T>();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -111,6 +111,7 @@ int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s, cons
 template <typename T>
 __global__ __launch_bounds__(256) void pack_channels_kernel(const float* __restrict__ src, int nch, int H, int W, const int32_t* __restrict__ patches,
                                                             int n, int p, T* __restrict__ x96, int c_total, int c_off) {
+    h16_mode_init<T>();
     const long long total = (long long)n * p * p * nch;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id % nch);
@@ -131,6 +132,7 @@ constexpr int PACK_MAX_P = 128, PACK_MAX_CH = 48;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_channels_rows_kernel(const float* __restrict__ src, int nch, int H, int W, const int32_t* __restrict__ patches,
                                                                  int p, T* __restrict__ x96, int c_total, int c_off) {
+    h16_mode_init<T>();
     __shared__ float tile[PACK_MAX_CH * (PACK_MAX_P + 1)];
     const int k = (int)(blockIdx.x / (unsigned)p), yy = (int)(blockIdx.x - (unsigned)k * (unsigned)p);
     int img = k, hi = 0, wi = 0;
@@ -266,6 +268,7 @@ int k_ddim_from_sums(const float* acc_cnt, const float* x_t, int nimg, int H, in
 // =================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW) {
+    h16_mode_init<T>();
     const long long total = (long long)B * C * HW;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id % C);
@@ -399,6 +402,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float4* __restrict__ st0, int nslab0, int C0, const float4* __restrict__ st1, int nslab1, int C,
                                                                 int HW, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 const T* __restrict__ x0, int xs0, const T* __restrict__ x1, int xs1, T* __restrict__ y, int silu) {
+    h16_mode_init<T>();
     constexpr int VEC = TI<T>::VEC;
     constexpr int GPW = 4;                            // groups per workgroup = waves per workgroup
     __shared__ float tab[2][GPW * 64];                // scale | shift of the workgroup's channels (group widths up to 64)
@@ -502,6 +506,7 @@ int k_gn_finalize_apply(int B, const Tens& x0, const Tens* x1, const float* st0,
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int xs, int C, int HW, long long nvec, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int sc_ld, T* __restrict__ y, int ys, int silu) {
+    h16_mode_init<T>();
     constexpr int VEC = TI<T>::VEC;
     const int cols = C / VEC;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec; id += (long long)gridDim.x * blockDim.x) {
@@ -530,6 +535,7 @@ int k_gn_apply(const Tens& x, int B, const float* scale, const float* shift, int
 // =================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, T* __restrict__ P, long long rows, int n) {
+    h16_mode_init<T>();
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -759,6 +765,7 @@ int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total
 // y[row][0..Cp) = x[row][0..C) followed by zeros (dense rows)
 template <typename T>
 __global__ __launch_bounds__(256) void pad_channels2_kernel(const T* __restrict__ x, int C, int Cp, T* __restrict__ y, long long total) {
+    h16_mode_init<T>();
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id % Cp);
         const long long r = id / Cp;

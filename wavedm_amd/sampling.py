@@ -77,7 +77,7 @@ _GRAPHS = None
 _GRAPH_CACHE = int(os.environ.get("WAVEDM_GRAPH_CACHE", "6"))        # captured loops kept (least recently used first out): each holds its activations' memory pool
 
 
-def _replay_graph(unet, run_loop, x, x_cond, x_other, n_run, key_tail):
+def _replay_graph(unet, run_loop, x, x_cond, x_other, n_run, key_tail, keepalive=()):
     global _GRAPHS
     from collections import OrderedDict
     if _GRAPHS is None:
@@ -99,8 +99,8 @@ def _replay_graph(unet, run_loop, x, x_cond, x_other, n_run, key_tail):
         with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (other threads -- the PNG writer's -- keep using the device meanwhile)
             out_xs, out_x0 = run_loop(xs_, xc_, xo_, n_run, False)
         # the entry keeps alive what the captured launches point at: the packed weights and the workspace of this moment (the model may replace either later)
-        # ... and, through the loop's closure, the patch list and the timestep tensor of THIS call (a later call's are other tensors)
-        ent = (g, xs_, xc_, xo_, out_xs, out_x0, packed, dict(unet._ws), run_loop)
+        # ... and the device tensors of THIS call the launches read through raw pointers (patch list, timesteps): a later call makes its own
+        ent = (g, xs_, xc_, xo_, out_xs, out_x0, packed, dict(unet._ws), run_loop, tuple(keepalive))
         _GRAPHS[key] = ent
         while len(_GRAPHS) > max(1, _GRAPH_CACHE):
             _GRAPHS.popitem(last=False)
@@ -283,7 +283,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                    not torch.cuda.is_current_stream_capturing())
         if graphed:
             xs, x0_preds = _replay_graph(unet, run_loop, x, x_cond, x_other, n_run,
-                                         (tuple(seq), None if corners is None else tuple(map(tuple, tri)), p, max_batch, keep_set, n_run, betas.detach().float().cpu().numpy().tobytes()))
+                                         (tuple(seq), None if corners is None else tuple(map(tuple, tri)), p, max_batch, keep_set, n_run, betas.detach().float().cpu().numpy().tobytes()),
+                                         keepalive=(patches, t_dev))
         else:
             xs, x0_preds = run_loop(x, x_cond, x_other, n_run, multi)
         if keep != "all":
