@@ -336,7 +336,8 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         __builtin_amdgcn_s_barrier();                                      // every wave is done with the operand images the epilogue tile overlays
         __builtin_amdgcn_sched_barrier(0);
         // the workgroup's 64 queries are rows 4 qb ... 4 qb + 3 of the image's 16 x 16 map: wave row `qb` of a 256-pixel tile; its 8 waves are 8 column blocks
-        conv_epilogue<T, 16, 16, 4, 4, 4>(pe, y_acc, smem, true, wave, lane, qb, wave, b, 0, 0, 0, 0, 0, EpiNoHook(), false);
+        // (round 5: the 16-bit-tile epilogue takes the residual as well -- conv_kernel.h: conv_epilogue_packed --: same bits, a third of the fp32 tile's LDS traffic, none of its bank conflicts)
+        conv_epilogue<T, 16, 16, 4, 4, 4, EpiNoHook, false, 1>(pe, y_acc, smem, true, wave, lane, qb, wave, b, 0, 0, 0, 0, 0, EpiNoHook(), false);
         gn_arrive<C::NTHREADS>(pe, b, 1, 256, (int*)smem, (int)threadIdx.x);       // four query blocks complete an image
     }
 }
