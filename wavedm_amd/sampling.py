@@ -60,8 +60,14 @@ def overlapping_grid_indices(h, w, output_size, r=None):
 
 
 def _chunk_streams(dev, n):
-    """Side streams of the chunked sampler: fresh ones from torch's pool per call.  (Measured, round 3: the SAME four streams used pass after pass ran 35 %
-    slower than one stream on every box tried, streams taken round-robin from the pool mostly did not -- see EXPERIMENTS.md; this is why `streams` is opt-in.)"""
+    """Side streams of the chunked sampler: fresh ones from torch's pool per call.
+    Root cause of the "-35 % on reused streams" of rounds 3-4 (round 5, profiles/r05_streams_hw_queues.log): it is the HIP runtime's stream -> HARDWARE QUEUE
+    mapping (GPU_MAX_HW_QUEUES, default 4), not the streams' age.  Whenever two chunks' streams sit on DIFFERENT hardware queues their kernels really run side by
+    side -- and that is what costs 35 % (2 streams on 4 or 8 queues: 400-423 img/s against 615-619 on one stream; 4 streams on 8 queues 371; 8 on 16: 247): every
+    workgroup of these kernels takes a whole CU's LDS, so two launches only split the CUs between them while each streams its own weights and halo tiles through
+    the caches, and the tile rules that count one launch's workgroups per round no longer describe what a CU sees.  When the chunks' streams SHARE a queue (2 streams
+    with GPU_MAX_HW_QUEUES=2: 627.6; 4 streams on the default 4 queues, which the main stream and torch's pool also use: 628.4) the launches serialise on it and the
+    result is the single-stream rate +- 2 %.  So there is nothing to win here, and the mode stays opt-in."""
     return [torch.cuda.Stream(device=dev) for _ in range(n)]
 
 
@@ -140,10 +146,9 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
           the lists are padded with None so indices keep their meaning.  Default None = run every step like the reference.
     streams: OPT-IN (default WAVEDM_STREAMS or 1).  Independent crops (corners=None) are split into this many chunks, each walking its whole trajectory on a
           HIP stream of its own (own UNet workspace), so that one chunk's kernels can fill the launch boundaries and tails of the others'.  Per-image results do
-          not depend on the batch an image sits in: the same bits as one stream (tests/test_gpu_unet.py).  Measured with 4 streams: +5 % on a box whose
-          single-stream rate was 120 img/s, +-0 on one at 127, and -35 % whenever the same four streams are reused pass after pass or five or more are
-          active (the device has four hardware queues) -- not understood well enough to be a default.  Patch lists (overlap sums couple an image's patches
-          every step) and per-launch profiling always run on one stream.
+          not depend on the batch an image sits in: the same bits as one stream (tests/test_gpu_unet.py).  Measured: +-2 % when the chunks' streams share a
+          hardware queue, -35 % when they do not (_chunk_streams: kernels that take a whole CU each do not gain from running side by side).  Patch lists (overlap
+          sums couple an image's patches every step) and per-launch profiling always run on one stream.
     patch_group: a torch.distributed process group (or True for the default group) = patch-sharded latency mode
           (SURVEY.md §8e-ii): the patch list is split contiguously over the ranks, each rank runs the UNet on its patches,
           and ONE all-reduce(sum) per step (RCCL) combines partial sums and overlap counts before the DDIM update, which every
