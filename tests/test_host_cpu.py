@@ -240,3 +240,19 @@ def test_parameter_order_is_the_references(golden):
     bound = 1.0 / (sd["down.0.block.0.conv1.weight"][0].numel() ** 0.5)
     assert float(b.abs().max()) <= bound and float(b.abs().max()) > 0.0
     assert float(sd["down.0.block.0.norm1.bias"].abs().max()) == 0.0 and float((sd["down.0.block.0.norm1.weight"] - 1).abs().max()) == 0.0
+
+
+def test_f16_mode_layout_is_the_bf16_layout_plus_the_range_flag():
+    """WDM_F16 (round 5): same packed layout and workspace as bf16 (2-byte elements, the same copies) plus one 256-byte slot for the weight loader's range flag;
+    the HFRM and the trainer map the mode to f32; unknown dtype names are refused."""
+    import wavedm_amd
+    cfg = P.raindrop_wavelet_config()
+    a, b = wavedm_amd.DiffusionUNet(cfg, dtype="bf16"), wavedm_amd.DiffusionUNet(cfg, dtype="f16")
+    assert b._dtype_code == _lib.WDM_F16 and b._torch_dtype == torch.float16
+    assert b.packed_bytes() == a.packed_bytes() + 256
+    L = _lib.lib()
+    assert int(L.wdm_unet_workspace_bytes(b._u, 8)) == int(L.wdm_unet_workspace_bytes(a._u, 8))
+    from wavedm_amd.arch import HFRM
+    assert HFRM(in_channel=3, dim=32, mid_blk_num=1, enc_blk_nums=[1], dec_blk_nums=[1], dtype="f16")._dtype_code == _lib.WDM_F32
+    with pytest.raises(ValueError):
+        wavedm_amd.DiffusionUNet(cfg, dtype="fp8")
