@@ -29,6 +29,10 @@ import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+# What the board SUSTAINS on random 16-bit operands with nothing but MFMAs in flight (register-resident v_mfma_f32_16x16x32 loop, no LDS / memory traffic:
+# tools/mfma_power_ubench.hip, profiles/r05_mfma_power_ubench.log -- 1 845 TFLOP/s against 2 476 on all-zero operands: the power limit, not the pipe).  `roofline.peak`
+# stays the nominal figure the contract names; `roofline.sustained` prices the same achieved rate against this one.
+MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS = 1845.0
 
 
 def log(*a):
@@ -251,6 +255,10 @@ def main():
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "all_conv_tflops": round(sum(e["flops"] for e in rep) / tot_ms / 1e9, 2),
                     "conv_ms_per_pass": round(tot_ms, 2)}
+        if args.dtype in ("bf16", "f16"):
+            roofline["sustained"] = {"peak": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, 4),
+                                     "what": "register-resident 16x16x32 MFMA loop on random 16-bit operands, measured on this board class (power-limited; 2476 on zeros): "
+                                             "profiles/r05_mfma_power_ubench.log"}
         # Since round 3 the 3x3 stride-1 convs of the 16-pixel-multiple maps -- ONE kernel name until round 2 -- run as three tilings / schedules of the
         # same LDS-DMA design (256 x 128 persistent on the 64 x 64 maps, 256 x 128 on 16 x 16, 256 x 256 on 32 x 32), so "the dominant kernel" above is
         # the largest of the three; the family figure is the like-for-like successor of round 2's single-kernel number.
