@@ -180,6 +180,97 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- FIRST contraction into the accumulators (round 5: it used to be the second): the ResnetBlock's 1x1 shortcut over the block input (conv_dma_kernel.h /
+    // conv_gemm_kernel.h: 128-byte rows, 64 channels per K step, DMA ring over the operand buffers the 3x3 loop has not touched yet).  In this order the
+    // register allocator keeps the 128 accumulator registers where they are between the two K loops: with the 3x3 loop first it permuted them and spilled 56 of
+    // them in the 512 x 128 tile with the 16-bit-tile epilogue (that launch shape was stuck on the fp32 tile at 0.33 of the roof).  Every tiling of the family
+    // accumulates in the same order -- shortcut channels ascending, then (slab, dx, dy) --, so all of them still write the same bits.
+    if (SC && a.sx0 != nullptr) {
+        constexpr int G_ROWS = C::G_ROWS, G_APW = G_ROWS / 64, G_BPW = BN / 64, G_NBUF = C::G_NBUF;
+        constexpr int G_STAGE = C::G_STAGE, G_A = G_ROWS * 128;
+        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
+        // the 512-row tile has eight pixel pieces per wave and stage: their offsets are recomputed per stage (a dozen VALU beside 64 MFMAs) rather than
+        // held in sixteen registers next to the 128 accumulator registers
+        constexpr bool FLY = TH == 32;
+        unsigned g_a0[FLY ? 1 : G_APW], g_a1[FLY ? 1 : G_APW], g_b[G_BPW];
+        auto pix_off = [&](int i, int ll, unsigned& o0, unsigned& o1) __attribute__((always_inline)) {
+            const int row = (wave * G_APW + i) * 8 + (ll >> 3);
+            const int u = (ll & 7) ^ ((row >> 1) & 7);
+            const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
+            o0 = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
+            o1 = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
+        };
+        if (!FLY) {
+#pragma unroll
+            for (int i = 0; i < G_APW; ++i) pix_off(i, lane, g_a0[FLY ? 0 : i], g_a1[FLY ? 0 : i]);
+        }
+#pragma unroll
+        for (int i = 0; i < G_BPW; ++i) {
+            const int row = (wave * G_BPW + i) * 8 + (lane >> 3);
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
+        }
+        auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
+            const int c = k * 64;
+            const unsigned base = lds0 + buf * G_STAGE;
+            int ll = lane;
+            if (FLY) asm volatile("" : "+v"(ll));              // (keeps the offsets from being hoisted out of the stage loop)
+            const bool first = c < a.sC0;
+            const i32x4 q_s = first ? q_s0 : q_s1;
+            const int cs = (first ? c : c - a.sC0) * 2;
+#pragma unroll
+            for (int i = 0; i < G_APW; ++i) {
+                unsigned o0, o1;
+                if (FLY) pix_off(i, ll, o0, o1); else { o0 = g_a0[FLY ? 0 : i]; o1 = g_a1[FLY ? 0 : i]; }
+                dma16(q_s, base + (wave * G_APW + i) * 1024, first ? o0 : o1, cs);
+            }
+#pragma unroll
+            for (int i = 0; i < G_BPW; ++i) dma16(q_sw, base + G_A + (wave * G_BPW + i) * 1024, g_b[i], c * 2);
+        };
+        const int sw7 = (lane >> 1) & 7;
+        int a2[2], b2[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = (ks * 4 + ku) ^ sw7;
+            a2[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
+            b2[ks] = G_A + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
+        }
+        const int nk = (a.sC0 + a.sC1) / 64;
+        issue2(0, 0);
+        if (G_NBUF == 3 && nk > 1) issue2(1, 1);
+        int buf = 0;
+        for (int k = 0; k < nk; ++k) {
+            if (G_NBUF == 3 && k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G_APW + G_BPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (G_NBUF == 3) { if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2); }
+            else if (k + 1 < nk) issue2(k + 1, buf ^ 1);
+            if (FLY) __builtin_amdgcn_sched_barrier(0);         // (offsets, requests, then fragments: all three at once do not fit beside 128 accumulator registers)
+            const char* base = smem + buf * G_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (FLY && ks) __builtin_amdgcn_sched_barrier(0);
+                uint4 af[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    uint4 bfr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfr[j] = *(const uint4*)(base + b2[ks] + (h * 4 + j) * (16 * 128));
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16t<T>(acc[i][h * 4 + j], af[i], bfr[j]);
+                }
+            }
+            buf = buf + 1 == G_NBUF ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     auto mfma_dx = [&](int s, int dx, int slot) __attribute__((always_inline)) {
         if ((WDM_DABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
@@ -275,94 +366,6 @@ __global__ __launch_bounds__(512, 2) void conv_dma256_kernel(const ConvArgs a) {
 #undef WDM_DMA_SYNC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the clamped column requested last must not land on what follows
     __builtin_amdgcn_sched_barrier(0);
-
-    // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (conv_dma_kernel.h / conv_gemm_kernel.h:
-    // 128-byte rows, 64 channels per K step, DMA ring over the now idle operand buffers)
-    if (SC && a.sx0 != nullptr) {
-        constexpr int G_ROWS = C::G_ROWS, G_APW = G_ROWS / 64, G_BPW = BN / 64, G_NBUF = C::G_NBUF;
-        constexpr int G_STAGE = C::G_STAGE, G_A = G_ROWS * 128;
-        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
-        // the 512-row tile has eight pixel pieces per wave and stage: their offsets are recomputed per stage (a dozen VALU beside 64 MFMAs) rather than
-        // held in sixteen registers next to the 128 accumulator registers
-        constexpr bool FLY = TH == 32;
-        unsigned g_a0[FLY ? 1 : G_APW], g_a1[FLY ? 1 : G_APW], g_b[G_BPW];
-        auto pix_off = [&](int i, int ll, unsigned& o0, unsigned& o1) __attribute__((always_inline)) {
-            const int row = (wave * G_APW + i) * 8 + (ll >> 3);
-            const int u = (ll & 7) ^ ((row >> 1) & 7);
-            const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
-            o0 = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
-            o1 = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
-        };
-        if (!FLY) {
-#pragma unroll
-            for (int i = 0; i < G_APW; ++i) pix_off(i, lane, g_a0[FLY ? 0 : i], g_a1[FLY ? 0 : i]);
-        }
-#pragma unroll
-        for (int i = 0; i < G_BPW; ++i) {
-            const int row = (wave * G_BPW + i) * 8 + (lane >> 3);
-            const int u = (lane & 7) ^ ((row >> 1) & 7);
-            const int n = n0 + row;
-            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
-        }
-        auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
-            const int c = k * 64;
-            const unsigned base = lds0 + buf * G_STAGE;
-            int ll = lane;
-            if (FLY) asm volatile("" : "+v"(ll));              // (keeps the offsets from being hoisted out of the stage loop)
-            const bool first = c < a.sC0;
-            const i32x4 q_s = first ? q_s0 : q_s1;
-            const int cs = (first ? c : c - a.sC0) * 2;
-#pragma unroll
-            for (int i = 0; i < G_APW; ++i) {
-                unsigned o0, o1;
-                if (FLY) pix_off(i, ll, o0, o1); else { o0 = g_a0[FLY ? 0 : i]; o1 = g_a1[FLY ? 0 : i]; }
-                dma16(q_s, base + (wave * G_APW + i) * 1024, first ? o0 : o1, cs);
-            }
-#pragma unroll
-            for (int i = 0; i < G_BPW; ++i) dma16(q_sw, base + G_A + (wave * G_BPW + i) * 1024, g_b[i], c * 2);
-        };
-        const int sw7 = (lane >> 1) & 7;
-        int a2[2], b2[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = (ks * 4 + ku) ^ sw7;
-            a2[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
-            b2[ks] = G_A + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
-        }
-        const int nk = (a.sC0 + a.sC1) / 64;
-        issue2(0, 0);
-        if (G_NBUF == 3 && nk > 1) issue2(1, 1);
-        int buf = 0;
-        for (int k = 0; k < nk; ++k) {
-            if (G_NBUF == 3 && k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G_APW + G_BPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (G_NBUF == 3) { if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2); }
-            else if (k + 1 < nk) issue2(k + 1, buf ^ 1);
-            if (FLY) __builtin_amdgcn_sched_barrier(0);         // (offsets, requests, then fragments: all three at once do not fit beside 128 accumulator registers)
-            const char* base = smem + buf * G_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (FLY && ks) __builtin_amdgcn_sched_barrier(0);
-                uint4 af[WM];
-#pragma unroll
-                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    uint4 bfr[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bfr[j] = *(const uint4*)(base + b2[ks] + (h * 4 + j) * (16 * 128));
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) mma16t<T>(acc[i][h * 4 + j], af[i], bfr[j]);
-                }
-            }
-            buf = buf + 1 == G_NBUF ? 0 : buf + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- epilogue: every 64-pixel x 64-channel block of a wave goes through conv_epilogue at the place it has in the 16 x 16 / 128-column tiling
     // (same rows per statistics slab, same slab index, same association): the 8 x 16 tile is the upper or lower half of a 16 x 16 one, the 32 x 16 tile two of them

@@ -189,6 +189,79 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- FIRST contraction into the accumulators (round 5: before the 3x3 loop, like every tiling of the family -- conv_dma256_kernel.h says why): the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1).
+    // Plain GEMM over the tile's 256 pixels: conv_gemm_kernel.h's loop (128-byte rows, 64 channels per K step, ring of three
+    // 48 KB stages over the now idle operand buffers, DMA two stages ahead).
+    if (a.sx0 != nullptr) {
+        constexpr int G_ROWS = TH * 16, G_APW = G_ROWS / 64, G_NBUF = C::G_NBUF;      // A pieces (8 rows of 128 B) per wave and stage: 4
+        constexpr int G_STAGE = G_ROWS * 128 + BN * 128, G_A = G_ROWS * 128;
+        static_assert(G_NBUF * G_STAGE <= C::LDS_BYTES && C::NWAVES == 8, "shortcut ring");
+        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
+        unsigned g_a0[G_APW], g_a1[G_APW], g_b[2];
+#pragma unroll
+        for (int i = 0; i < G_APW; ++i) {
+            const int row = (wave * G_APW + i) * 8 + (lane >> 3);
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
+            g_a0[i] = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
+            g_a1[i] = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
+        }
+        auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
+            const int c = k * 64;
+            const unsigned base = lds0 + buf * G_STAGE;
+            if (c < a.sC0) {
+#pragma unroll
+                for (int i = 0; i < G_APW; ++i) dma16(q_s0, base + (wave * G_APW + i) * 1024, g_a0[i], c * 2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < G_APW; ++i) dma16(q_s1, base + (wave * G_APW + i) * 1024, g_a1[i], (c - a.sC0) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16(q_sw, base + G_A + (wave * 2 + i) * 1024, g_b[i], c * 2);
+        };
+        const int sw7 = (lane >> 1) & 7;
+        int a2[2], b2[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = (ks * 4 + ku) ^ sw7;
+            a2[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
+            b2[ks] = G_A + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
+        }
+        const int nk = (a.sC0 + a.sC1) / 64;
+        issue2(0, 0);
+        if (G_NBUF == 3 && nk > 1) issue2(1, 1);
+        int buf = 0;
+        for (int k = 0; k < nk; ++k) {
+            if (G_NBUF == 3 && k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G_APW + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (G_NBUF == 3) { if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2); }
+            else if (k + 1 < nk) issue2(k + 1, buf ^ 1);          // two buffers: the next stage goes where stage k - 1 was, one stage of lead
+            const char* base = smem + buf * G_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(base + b2[ks] + j * (16 * 128));
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], af[i], bfr[j]);
+            }
+            buf = buf + 1 == G_NBUF ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     auto mfma_dx = [&](int s, int dx, int slot) __attribute__((always_inline)) {
         if ((WDM_DABL & 18) == 18) return;
         const char* pa = smem + (s & 1) * C::A_BYTES;
@@ -283,79 +356,6 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");            // no DMA may land on what follows
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- second contraction into the same accumulators: the ResnetBlock's 1x1 shortcut over the block input (a.sx0 | a.sx1).
-    // Plain GEMM over the tile's 256 pixels: conv_gemm_kernel.h's loop (128-byte rows, 64 channels per K step, ring of three
-    // 48 KB stages over the now idle operand buffers, DMA two stages ahead).
-    if (a.sx0 != nullptr) {
-        constexpr int G_ROWS = TH * 16, G_APW = G_ROWS / 64, G_NBUF = C::G_NBUF;      // A pieces (8 rows of 128 B) per wave and stage: 4
-        constexpr int G_STAGE = G_ROWS * 128 + BN * 128, G_A = G_ROWS * 128;
-        static_assert(G_NBUF * G_STAGE <= C::LDS_BYTES && C::NWAVES == 8, "shortcut ring");
-        const i32x4 q_s0 = make_q(a.sx0, a.sx0_bytes), q_s1 = make_q(a.sx1 ? a.sx1 : a.sx0, a.sx1_bytes), q_sw = make_q(a.sw, a.sw_bytes);
-        unsigned g_a0[G_APW], g_a1[G_APW], g_b[2];
-#pragma unroll
-        for (int i = 0; i < G_APW; ++i) {
-            const int row = (wave * G_APW + i) * 8 + (lane >> 3);
-            const int u = (lane & 7) ^ ((row >> 1) & 7);
-            const unsigned gp = (unsigned)((img0 * a.Hout + oy0 + row / TW) * a.Wout + ox0 + row % TW);
-            g_a0[i] = gp * (unsigned)(a.sxs0 * 2) + (unsigned)(u * 16);
-            g_a1[i] = gp * (unsigned)(a.sxs1 * 2) + (unsigned)(u * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 8 + (lane >> 3);
-            const int u = (lane & 7) ^ ((row >> 1) & 7);
-            const int n = n0 + row;
-            g_b[i] = n < a.sw_rows ? (unsigned)(n * a.sw_row_stride * 2 + u * 16) : OOB;
-        }
-        auto issue2 = [&](int k, int buf) __attribute__((always_inline)) {
-            const int c = k * 64;
-            const unsigned base = lds0 + buf * G_STAGE;
-            if (c < a.sC0) {
-#pragma unroll
-                for (int i = 0; i < G_APW; ++i) dma16(q_s0, base + (wave * G_APW + i) * 1024, g_a0[i], c * 2);
-            } else {
-#pragma unroll
-                for (int i = 0; i < G_APW; ++i) dma16(q_s1, base + (wave * G_APW + i) * 1024, g_a1[i], (c - a.sC0) * 2);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) dma16(q_sw, base + G_A + (wave * 2 + i) * 1024, g_b[i], c * 2);
-        };
-        const int sw7 = (lane >> 1) & 7;
-        int a2[2], b2[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = (ks * 4 + ku) ^ sw7;
-            a2[ks] = (wave_m * WM * 16 + (lane & 15)) * 128 + slot * 16;
-            b2[ks] = G_A + (wave_n * WN * 16 + (lane & 15)) * 128 + slot * 16;
-        }
-        const int nk = (a.sC0 + a.sC1) / 64;
-        issue2(0, 0);
-        if (G_NBUF == 3 && nk > 1) issue2(1, 1);
-        int buf = 0;
-        for (int k = 0; k < nk; ++k) {
-            if (G_NBUF == 3 && k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G_APW + 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (G_NBUF == 3) { if (k + 2 < nk) issue2(k + 2, buf >= 1 ? buf - 1 : 2); }
-            else if (k + 1 < nk) issue2(k + 1, buf ^ 1);          // two buffers: the next stage goes where stage k - 1 was, one stage of lead
-            const char* base = smem + buf * G_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 af[WM], bfr[WN];
-#pragma unroll
-                for (int i = 0; i < WM; ++i) af[i] = *(const uint4*)(base + a2[ks] + i * (16 * 128));
-#pragma unroll
-                for (int j = 0; j < WN; ++j) bfr[j] = *(const uint4*)(base + b2[ks] + j * (16 * 128));
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j) mma16t<T>(acc[i][j], af[i], bfr[j]);
-            }
-            buf = buf + 1 == G_NBUF ? 0 : buf + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
     // 16 x 16 maps: the tile is one whole image x BN columns -- the consumer's act(GroupNorm(y)) from here when it asked for it (gn_group.h; host check)
     using G = GnTailGeom<16, TW, 4, WN, WN, C::WAVES_N>;
     static_assert(G::total_bytes(C::NWAVES, 1, C::BN) <= C::LDS_BYTES, "in-tile GroupNorm: LDS");
