@@ -15,13 +15,21 @@ import pandas as pd
 
 
 def short(name: str) -> str:
-    """Mangled kernel name (rocprofv3 -M) -> readable id; conv_kernel<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>."""
-    m = re.search(r"conv_kernelI(DF16b|f|NS_7f32x3_tE)((?:Li\d+E)+)", name)
+    """Mangled kernel name (rocprofv3 -M) -> readable id; the 16-bit kernels are templates on the element type since round 5: DF16b = bf16, DF16_ = IEEE half."""
+    r = _short(name)
+    if r.endswith("_bf16") and "DF16_" in name and "DF16b" not in name:
+        r = r[:-5] + "_f16"
+    return r
+
+
+def _short(name: str) -> str:
+    """conv_kernel<T, MODE, TH, TW, NI, WAVES_M, WAVES_N, WM, WN>."""
+    m = re.search(r"conv_kernelI(DF16b|DF16_|f|NS_7f32x3_tE)((?:Li\d+E)+)", name)
     if m:
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(2))]
         if len(a) in (8, 9):
             mode = {0: "3x3s1", 1: "3x3s2", 2: "3x3ups", 3: "1x1"}[a[0]]
-            ty = {"DF16b": "bf16", "f": "f32"}.get(m.group(1), "f32x3")
+            ty = {"DF16b": "bf16", "DF16_": "f16", "f": "f32"}.get(m.group(1), "f32x3")
             return f"conv_{mode}_t{a[1]}x{a[2]}x{a[3]}_bn{16 * a[7] * a[5]}_{ty}"
     m = re.search(r"conv_dma_kernelI((?:Li\d+E)+)", name)
     if m:                                            # rounds 1-3: a template over the wave layout
@@ -30,10 +38,10 @@ def short(name: str) -> str:
     m = re.search(r"conv_dma_kernel(?:ILb(\d)E|<(true|false)>|E)", name)
     if m:                                            # round 4: one configuration, <true> = bf16-tile ("packed") epilogue, <false> = fp32 epilogue
         return f"convdma_3x3s1_t16x16x1_bn128w8{'p' if m.group(1) == '1' or m.group(2) == 'true' else ''}_bf16"
-    m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)(?:Lb(\d)E)?", name)
-    if m:
+    m = re.search(r"conv_dma256_kernelI((?:Li\d+E)+)(?:Lb(\d)E)?(?:Lb(\d)E)?", name)
+    if m:                                            # <..., TH, PACKED, SC>: "p" = 16-bit-tile epilogue, "s" = the 512 x 128 tile's binary with the shortcut phase
         a = [int(v) for v in re.findall(r"Li(\d+)E", m.group(1))]
-        return f"convdma_3x3s1_t{a[4]}x16x1_bn{16 * a[3] * a[1]}w8{'p' if m.group(2) == '1' else ''}_bf16"
+        return f"convdma_3x3s1_t{a[4]}x16x1_bn{16 * a[3] * a[1]}w8{'p' if m.group(2) == '1' else ''}{'s' if a[4] == 32 and m.group(3) == '1' else ''}_bf16"
     if "conv_dmap_kernel" in name:                   # <true>: packed epilogue, <false>: fp32 epilogue (residual convs) -- one name, as the library's profiler reports them
         return "convdmap_3x3s1_t16x16x1_bn128w8_bf16"
     m = re.search(r"conv_up4_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
