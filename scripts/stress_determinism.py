@@ -17,7 +17,7 @@ dev = torch.device("cuda", 0)
 cfg = P.raindrop_wavelet_config()
 cfg.device = dev
 args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm", test_set="raindrop", grid_r=16, max_batch=64)
-d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="bf16")
+d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype=os.environ.get("DTYPE", "bf16"))      # DTYPE=f16: the same screen for the fp16 instantiations
 d.model.load_state_dict(P.procedural_state_dict(cfg, seed=61), strict=True)
 rainy, x_T = P.synthetic_batch(64, patch_px=256, seed=61)
 rainy, x_T = rainy.to(dev), x_T.to(dev)
