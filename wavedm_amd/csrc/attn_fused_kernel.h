@@ -104,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     const int npass = Cc > C::MAX_CP ? 2 : 1;
     const int Cp = Cc / npass;
     const int p2 = Cp / 16;                                            // pieces per chunk (<= 32)
+    const bool own_rows = Cp == 512;                                   // every wave fetches exactly the 64 rows it reads (phases 2 and 3): no per-step workgroup barrier there
     const int un2 = (lane & 3) ^ ((lane >> 3) & 2);
     unsigned v2[4];
 #pragma unroll
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         for (int k = 0; k < N / 32; ++k) {
             if (k + 1 < N / 32) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // (k = 0: also makes every wave's P visible)
+            // own_rows (Cp = 512): a wave's V^T rows -- the channels it computes -- are exactly the rows it fetched itself (pieces 4 wave ... 4 wave + 3), and the ring
+            // slot it overwrites holds only rows it alone reads: its own counted wait is all the synchronisation a step needs.  Only k = 0 needs the workgroup (P)
+            if (k == 0 || !own_rows) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < N / 32) issue2(pass, k + 2, buf >= 1 ? buf - 1 : 2);
             const char* vb = smem + buf * C::ST2;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         for (int k = 0; k < nch; ++k) {
             if (k + 1 < nch) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                  // (k = 0: also makes every wave's part of the O image visible)
+            if (k == 0 || !own_rows) __builtin_amdgcn_s_barrier();          // k = 0: every wave's part of the O image is visible; afterwards a wave reads only the W_p rows it fetched itself
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < nch) issue3(k + 2, buf >= 1 ? buf - 1 : 2);
             const char* wb = smem + buf * ST3;
