@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--images-per-call", type=int, default=1, help="c4 only: loader items restored per sampler call (SURVEY.md §8f-2)")
     ap.add_argument("--max-batch", type=int, default=0, help="UNet call batch cap (default max(batch, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs of the default N=1 run (configs[2], configs[4], f32 parity mode)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs of the default N=1 run (configs[2], configs[4]) AND the parity modes")
+    ap.add_argument("--parity-only", action="store_true", help="with --no-extras: keep the parity-mode leg (f16 / f32x3 / f32 timed and checked), skip configs[2] / configs[4]")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     # stdout carries the ONE JSON line and nothing else: whatever the libraries underneath print (the restore() front end mirrors the reference's
@@ -318,7 +319,7 @@ def main():
 
     # ---- informational legs of the default N = 1 run (driver-observed numbers instead of prose)
     extras, parity_mode = None, None
-    if rank == 0 and world == 1 and args.workload == "c1" and not args.no_extras:
+    if rank == 0 and world == 1 and args.workload == "c1" and (not args.no_extras or args.parity_only):
         import contextlib, io
         extras = []
 
@@ -350,99 +351,100 @@ def main():
             _lib.prof_enable(False)
             return fl
 
-        # configs[4] per GPU: 8 whole 480x720 images per sampler call, 45 stitched 64x64 patches each, 50 DDIM steps
-        a4 = SimpleNamespace(**vars(a))
-        a4.sampling_timesteps, a4.images_per_call, a4.max_batch = 50, 8, 128
-        d.args = a4
-        g4 = torch.Generator().manual_seed(4)
-        loader4 = [(torch.rand(1, 6, 480, 720, generator=g4), f"img{k}", torch.zeros(1)) for k in range(8)]
-        rest4 = wavedm_amd.DiffusiveRestoration(d, a4, cfg, save_images=False)
+        if not args.no_extras:
+            # configs[4] per GPU: 8 whole 480x720 images per sampler call, 45 stitched 64x64 patches each, 50 DDIM steps
+            a4 = SimpleNamespace(**vars(a))
+            a4.sampling_timesteps, a4.images_per_call, a4.max_batch = 50, 8, 128
+            d.args = a4
+            g4 = torch.Generator().manual_seed(4)
+            loader4 = [(torch.rand(1, 6, 480, 720, generator=g4), f"img{k}", torch.zeros(1)) for k in range(8)]
+            rest4 = wavedm_amd.DiffusiveRestoration(d, a4, cfg, save_images=False)
 
-        def pass_c4():
-            with contextlib.redirect_stdout(io.StringIO()):
-                rest4.restore(loader4, validation="raindrop", r=16)
-        t4 = timed(pass_c4)
-        sp4 = spread()
-        a4.sampling_timesteps = 5
-        fl4 = conv_flops_per_pass(pass_c4) * 10
-        extras.append({"workload": "BASELINE.json configs[4] per GPU: 8 whole 480x720 images, 45 stitched 64x64 patches each (r = 16), 50 DDIM steps, "
-                                   "8 images per sampler call", "value": round(8 / t4, 3), "unit": "img/s", "ms_per_step": round(t4 * 1e3, 1),
-                       "steps": 3, "warmup": 1, "spread": sp4, "conv_tflops": round(fl4 / t4 / 1e12, 1)})
-        d.args = a
-        log(f"[bench] extra configs[4]: {8 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per 8 images)")
-        del rest4, loader4
-        # configs[4] through the WHOLE restore() pipeline: PNG files on disk -> wavedm_amd.datasets.RainDrop loader (PIL decode +
-        # LANCZOS resizes, pinned DataLoader) -> device HFRM with procedural weights (models/arch.py, once per image) -> DWT -> stitched 50-step sampler ->
-        # IDWT -> three PSNRs on the device -> 8-bit conversion on the device + seven PNGs per image through the asynchronous writer (flushed inside the clock)
-        try:
-            import tempfile, shutil, copy
-            import numpy as np
-            from PIL import Image
-            from wavedm_amd.datasets import RainDrop
-            root = tempfile.mkdtemp(prefix="wdm_c4_")
-            rng = np.random.default_rng(44)
-            for sub_ in ("raindrop_test", "train"):
-                for leaf in ("input", "gt"):
-                    os.makedirs(os.path.join(root, "raindrop", sub_, leaf))
-            for k in range(8):
-                clean = rng.integers(0, 256, (480, 720, 3), dtype=np.uint8)
-                drop = np.clip(clean.astype(np.int16) + rng.integers(-40, 41, (480, 720, 3)), 0, 255).astype(np.uint8)
-                Image.fromarray(drop).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
-                Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
-            cfg4 = copy.deepcopy(cfg)
-            cfg4.device = dev
-            cfg4.data.data_dir = root
-            cfg4.data.num_workers = 4
-            a5 = SimpleNamespace(**vars(a))
-            a5.sampling_timesteps, a5.images_per_call, a5.max_batch, a5.world_size, a5.rank = 50, 8, 128, 1, 0
-            a5.image_folder = os.path.join(root, "out")
-            d.args = a5
-            ident = d.generator
-            d.generator = d._make_generator("procedural", args.dtype)
-            rest5 = wavedm_amd.DiffusiveRestoration(d, a5, cfg4, save_images=True)
-
-            def pass_c4_real():
+            def pass_c4():
                 with contextlib.redirect_stdout(io.StringIO()):
-                    _, val_loader = RainDrop(a5, cfg4).get_loaders(parse_patches=False, validation="raindrop")
-                    rest5.restore(val_loader, validation="raindrop", r=16)          # ends with writer.flush(): every PNG is on disk
-            t5 = timed(pass_c4_real)
-            n_png = len(os.listdir(os.path.join(a5.image_folder, cfg4.data.dataset, "raindrop")))
-            extras.append({"workload": "BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: 8 PNG pairs on disk -> RainDrop loader (PIL, 4 workers) -> device HFRM "
-                                       "(procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, 50 DDIM steps, 8 images per sampler call -> "
-                                       "IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
-                           "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 3, "warmup": 1, "spread": spread(), "pngs_written": n_png,
-                           "vs_identity_standin_leg": round(t4 / t5, 3)})
-            log(f"[bench] extra configs[4] whole pipeline (real HFRM, loader, PNGs): {8 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per 8 images, {n_png} PNGs)")
-            rest5.writer.close()
-            d.generator = ident
+                    rest4.restore(loader4, validation="raindrop", r=16)
+            t4 = timed(pass_c4)
+            sp4 = spread()
+            a4.sampling_timesteps = 5
+            fl4 = conv_flops_per_pass(pass_c4) * 10
+            extras.append({"workload": "BASELINE.json configs[4] per GPU: 8 whole 480x720 images, 45 stitched 64x64 patches each (r = 16), 50 DDIM steps, "
+                                       "8 images per sampler call", "value": round(8 / t4, 3), "unit": "img/s", "ms_per_step": round(t4 * 1e3, 1),
+                           "steps": 3, "warmup": 1, "spread": sp4, "conv_tflops": round(fl4 / t4 / 1e12, 1)})
             d.args = a
-            del rest5
-            shutil.rmtree(root, ignore_errors=True)
-        except Exception as e:                                      # the informational leg must not take the headline down with it
-            log(f"[bench] extra configs[4] whole pipeline FAILED: {type(e).__name__}: {e}")
-            extras.append({"workload": "BASELINE.json configs[4] whole restore() pipeline", "value": None, "error": f"{type(e).__name__}: {e}"})
-            d.args = a
-        # configs[2]: 128x128 wavelet-domain patches, batch 256, 100 steps (its own 163 M-parameter UNet: attention sits one level deeper)
-        cfg2 = P.raindrop_wavelet_config(image_size=128)
-        cfg2.device = dev
-        a2 = SimpleNamespace(**vars(a))
-        a2.sampling_timesteps, a2.max_batch = 100, 64
-        d2 = wavedm_amd.DenoisingDiffusion_Wavelet(a2, cfg2, generator=lambda x: x, dtype=args.dtype)
-        d2.model.load_state_dict(P.procedural_state_dict(cfg2, seed=61), strict=True)
-        r2, x2 = P.synthetic_batch(256, patch_px=512, seed=62)
-        r2, x2 = r2.to(dev), x2.to(dev)
-        a2.sampling_timesteps = 10
-        d2.restore_batch(r2, x2)                                            # warm-up: 10 steps of the same shapes (first-use costs, clocks)
-        a2.sampling_timesteps = 100
-        t2 = timed(lambda: d2.restore_batch(r2, x2), n_warm=0)
-        sp2 = spread()
-        a2.sampling_timesteps = 5
-        fl2 = conv_flops_per_pass(lambda: d2.restore_batch(r2, x2)) * 20
-        extras.append({"workload": "BASELINE.json configs[2]: 256 patches of 128x128 (512x512 px crops), 100 DDIM steps", "value": round(256 / t2, 3),
-                       "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 3, "warmup": "10 DDIM steps of the same batch", "spread": sp2, "conv_tflops": round(fl2 / t2 / 1e12, 1)})
-        log(f"[bench] extra configs[2]: {256 / t2:.2f} img/s ({t2:.2f} s per 256 patches)")
-        del d2, r2, x2
-        torch.cuda.empty_cache()
+            log(f"[bench] extra configs[4]: {8 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per 8 images)")
+            del rest4, loader4
+            # configs[4] through the WHOLE restore() pipeline: PNG files on disk -> wavedm_amd.datasets.RainDrop loader (PIL decode +
+            # LANCZOS resizes, pinned DataLoader) -> device HFRM with procedural weights (models/arch.py, once per image) -> DWT -> stitched 50-step sampler ->
+            # IDWT -> three PSNRs on the device -> 8-bit conversion on the device + seven PNGs per image through the asynchronous writer (flushed inside the clock)
+            try:
+                import tempfile, shutil, copy
+                import numpy as np
+                from PIL import Image
+                from wavedm_amd.datasets import RainDrop
+                root = tempfile.mkdtemp(prefix="wdm_c4_")
+                rng = np.random.default_rng(44)
+                for sub_ in ("raindrop_test", "train"):
+                    for leaf in ("input", "gt"):
+                        os.makedirs(os.path.join(root, "raindrop", sub_, leaf))
+                for k in range(8):
+                    clean = rng.integers(0, 256, (480, 720, 3), dtype=np.uint8)
+                    drop = np.clip(clean.astype(np.int16) + rng.integers(-40, 41, (480, 720, 3)), 0, 255).astype(np.uint8)
+                    Image.fromarray(drop).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
+                    Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
+                cfg4 = copy.deepcopy(cfg)
+                cfg4.device = dev
+                cfg4.data.data_dir = root
+                cfg4.data.num_workers = 4
+                a5 = SimpleNamespace(**vars(a))
+                a5.sampling_timesteps, a5.images_per_call, a5.max_batch, a5.world_size, a5.rank = 50, 8, 128, 1, 0
+                a5.image_folder = os.path.join(root, "out")
+                d.args = a5
+                ident = d.generator
+                d.generator = d._make_generator("procedural", args.dtype)
+                rest5 = wavedm_amd.DiffusiveRestoration(d, a5, cfg4, save_images=True)
+
+                def pass_c4_real():
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        _, val_loader = RainDrop(a5, cfg4).get_loaders(parse_patches=False, validation="raindrop")
+                        rest5.restore(val_loader, validation="raindrop", r=16)          # ends with writer.flush(): every PNG is on disk
+                t5 = timed(pass_c4_real)
+                n_png = len(os.listdir(os.path.join(a5.image_folder, cfg4.data.dataset, "raindrop")))
+                extras.append({"workload": "BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: 8 PNG pairs on disk -> RainDrop loader (PIL, 4 workers) -> device HFRM "
+                                           "(procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, 50 DDIM steps, 8 images per sampler call -> "
+                                           "IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
+                               "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 3, "warmup": 1, "spread": spread(), "pngs_written": n_png,
+                               "vs_identity_standin_leg": round(t4 / t5, 3)})
+                log(f"[bench] extra configs[4] whole pipeline (real HFRM, loader, PNGs): {8 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per 8 images, {n_png} PNGs)")
+                rest5.writer.close()
+                d.generator = ident
+                d.args = a
+                del rest5
+                shutil.rmtree(root, ignore_errors=True)
+            except Exception as e:                                      # the informational leg must not take the headline down with it
+                log(f"[bench] extra configs[4] whole pipeline FAILED: {type(e).__name__}: {e}")
+                extras.append({"workload": "BASELINE.json configs[4] whole restore() pipeline", "value": None, "error": f"{type(e).__name__}: {e}"})
+                d.args = a
+            # configs[2]: 128x128 wavelet-domain patches, batch 256, 100 steps (its own 163 M-parameter UNet: attention sits one level deeper)
+            cfg2 = P.raindrop_wavelet_config(image_size=128)
+            cfg2.device = dev
+            a2 = SimpleNamespace(**vars(a))
+            a2.sampling_timesteps, a2.max_batch = 100, 64
+            d2 = wavedm_amd.DenoisingDiffusion_Wavelet(a2, cfg2, generator=lambda x: x, dtype=args.dtype)
+            d2.model.load_state_dict(P.procedural_state_dict(cfg2, seed=61), strict=True)
+            r2, x2 = P.synthetic_batch(256, patch_px=512, seed=62)
+            r2, x2 = r2.to(dev), x2.to(dev)
+            a2.sampling_timesteps = 10
+            d2.restore_batch(r2, x2)                                            # warm-up: 10 steps of the same shapes (first-use costs, clocks)
+            a2.sampling_timesteps = 100
+            t2 = timed(lambda: d2.restore_batch(r2, x2), n_warm=0)
+            sp2 = spread()
+            a2.sampling_timesteps = 5
+            fl2 = conv_flops_per_pass(lambda: d2.restore_batch(r2, x2)) * 20
+            extras.append({"workload": "BASELINE.json configs[2]: 256 patches of 128x128 (512x512 px crops), 100 DDIM steps", "value": round(256 / t2, 3),
+                           "unit": "img/s", "ms_per_step": round(t2 * 1e3, 1), "steps": 3, "warmup": "10 DDIM steps of the same batch", "spread": sp2, "conv_tflops": round(fl2 / t2 / 1e12, 1)})
+            log(f"[bench] extra configs[2]: {256 / t2:.2f} img/s ({t2:.2f} s per 256 patches)")
+            del d2, r2, x2
+            torch.cuda.empty_cache()
         # parity modes: fp32 tensors end to end -- the modes that meet north_star's 1e-3.  "f32x3" (fast): every product of the contractions
         # as three bf16 MFMAs on hi/lo-split operands; "f32" (exact): v_mfma_f32_16x16x4_f32 chains, bit-for-bit fp32 FMA order.
         def rel(u, v):

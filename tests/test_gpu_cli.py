@@ -49,3 +49,20 @@ def test_train_then_eval_from_yaml(tmp_path):
     out = run(["eval", "--config", str(tmp_path / "configs" / "reduced.yml"), "--resume", str(ck), "--ema", "--no_save", "--sampling_timesteps", "5",
                "--grid_r", "8", "--image_folder", str(tmp_path / "img2")], cwd=str(tmp_path))
     assert out.count("=> loaded checkpoint") == 2 and not (tmp_path / "img2").exists()
+
+
+def test_bench_parity_mode_is_the_fastest_conformant_mode():
+    """bench.py's contract for `parity_mode` (round 5): the FASTEST mode whose full-length deviation measured <= 1e-3 in that very run -- f16 on this build -- with the
+    fp32-tensor mode and the exact mode beside it; a reduced call (8 crops, 10 DDIM steps) exercises the whole leg."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--batch", "8", "--ddim-steps", "10", "--steps", "1", "--warmup", "1", "--no-extras",
+                        "--parity-only", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    pm = line["parity_mode"]
+    assert pm["dtype"] == "f16" and pm["rel_linf_vs_f32_full_length"] <= 1e-3 and pm["value"] > pm["f32x3"]["value"] > pm["exact_f32"]["value"]
+    assert pm["f32x3"]["rel_linf_vs_f32_full_length"] <= 1e-4 and pm["roofline"]["peak"] == 2500.0
+    assert line["dtype"] == "bf16" and line["roofline"]["sustained"]["peak"] == 1845.0 and line["roofline"]["frac"] < line["roofline"]["sustained"]["frac"]
