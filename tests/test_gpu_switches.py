@@ -97,6 +97,36 @@ def test_proj_out_fused_into_the_attention_core_gives_the_same_bits(gu):
         assert rel_linf(y, gu.attn(sd, "at", x, "f32")) <= gu.TOL["bf16"]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_attention_block_on_folded_operands(gu, dtype):
+    """16-bit modes (blocks.hip: run_attn): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((Wk^T Wq h_i + Wk^T bq).h_j) and proj_out(P.(Wv h + bv)) = (Wp Wv)(P.h) + Wp bv + bp, so
+    the block runs ONE projection GEMM and the fused core with the normalised input as K and as (token-major, transposing-read) V.  WDM_ATTN_FOLD=0 keeps the k / v
+    projections: both forms meet the mode's bound against exact fp32, and the folded one launches fewer kernels."""
+    from wavedm_amd import _lib
+    for C, B in ((512, 5), (256, 3), (128, 9), (768, 2), (1024, 1)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("at", shapes)
+        x = gu.seeded((B, C, 16, 16), 9)
+
+        def run():
+            _lib.prof_enable(True)
+            out = gu.attn(sd, "at", x, dtype)
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+            _lib.prof_enable(False)
+            return out, names
+        (y, k1), (y0, k0) = run(), _with({"WDM_ATTN_FOLD": "0"}, run)
+        ref = gu.attn(sd, "at", x, "f32")
+        e1, e0 = rel_linf(y, ref), rel_linf(y0, ref)
+        print(f"attn {dtype} C={C}: folded {e1:.2e}  k / v projections {e0:.2e}")
+        assert torch.isfinite(y).all() and e1 <= gu.TOL[dtype] and e0 <= gu.TOL[dtype]
+        assert any(n.startswith("attn_fused_n256t_") for n in k1) and not any(n.startswith("attn_fused_n256t_") for n in k0), (k1, k0)
+        assert len(k1) == len(k0) - 1, (k1, k0)                      # q' instead of q|k and V^T
+        assert torch.equal(y, run()[0])
+
+
 def test_in_tile_groupnorm_of_the_producing_conv_gives_the_bits_of_the_pass(gu):
     """gn_group.h: gn_out_tail -- conv1 of an 8x8 ResnetBlock writes act(norm2(h)) itself (two whole images x two whole groups per 128 x 48 tile of
     conv_dma8_kernel.h) instead of a gn_finalize_apply launch (WDM_GN_TILE=0).  Same reduction (gn_group_stats over the same float4 partials), same

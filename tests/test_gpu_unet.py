@@ -472,6 +472,49 @@ def test_f16_weight_outside_the_fp16_range_is_refused():
     good.load_state_dict(sd, strict=True)
     good.cuda().pack_weights()
     assert torch.isfinite(good(seeded((1, 96, 16, 16), 3).cuda(), torch.tensor([10.0]))).all()
+    # ... and so is a FOLDED AttnBlock operand (Wk^T Wq) that leaves the range although both factors are inside it
+    kq = next(k for k in sd if k.endswith("attn.0.q.weight"))
+    kk = kq.replace(".q.", ".k.")
+    big = dict(sd)
+    c = sd[kq].shape[0]
+    big[kq] = (300.0 * torch.eye(c)).reshape(c, c, 1, 1)
+    big[kk] = (300.0 * torch.eye(c)).reshape(c, c, 1, 1)
+    net = wavedm_amd.DiffusionUNet(cfg, dtype="f16")
+    net.load_state_dict(big, strict=True)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        net.cuda().pack_weights()
+
+
+def test_attention_folding_follows_the_tensors_in_whatever_order_they_arrive():
+    """16-bit modes run the AttnBlocks on folded operands (Wk^T Wq, Wp Wv: csrc/unet.hip: refold), rebuilt by wdm_unet_load_param from fp32 originals kept beside the
+    packed matrices: the result does not depend on the order of the loads, and reloading ONE tensor of a block moves the folded operand with it."""
+    import ctypes as C
+    import wavedm_amd
+    from wavedm_amd import _lib, procedural as P
+    cfg = P.raindrop_wavelet_config()
+    sd = P.procedural_state_dict(cfg)
+    x, t = seeded((2, 96, 64, 64), 5).cuda(), torch.tensor([300.0, 20.0])
+    a = build(cfg, "f16")
+    ya = a(x, t)
+    b = wavedm_amd.DiffusionUNet(cfg, dtype="f16")
+    b.load_state_dict(sd, strict=True)
+    b = b.cuda()
+    b._names = list(reversed(b._names))
+    yb = b(x, t)
+    assert torch.isfinite(ya).all() and torch.equal(ya, yb)
+    # one tensor of one block changes: load it alone into `a`, everything into a fresh model
+    sd2 = dict(sd)
+    for key in ("down.2.attn.0.k.weight", "up.2.attn.1.proj_out.bias", "up.2.attn.2.v.weight"):
+        sd2[key] = sd[key] * 1.25 + 0.01
+        src = sd2[key].cuda().contiguous()
+        _lib.check(_lib.lib().wdm_unet_load_param(a._u, key.encode(), _lib.ptr(src), src.numel(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    c = wavedm_amd.DiffusionUNet(cfg, dtype="f16")
+    c.load_state_dict(sd2, strict=True)
+    yc = c.cuda()(x, t)
+    a._packed_sig = a._signature()
+    ya2 = a(x, t)
+    assert torch.equal(ya2, yc) and not torch.equal(ya2, ya)
 
 
 def test_sampling_loop_replayed_from_a_hipgraph_gives_the_same_bits():

@@ -142,6 +142,16 @@ int wdm_attn_forward(wdm_handle* h, const wdm_attn_params* p, const float* x, in
     w.qk.w = qkw; w.qk.b = qkb; w.qk.cin = C; w.qk.cout = 2 * C; w.qk.k = 1; w.qk.rows_pad = rows;
     WDM_TRY(pack_conv_w(sc, p->v_w, p->v_b, C, C, 1, dtype, c.s, &w.v));
     WDM_TRY(pack_conv_w(sc, p->proj_w, p->proj_b, C, C, 1, dtype, c.s, &w.proj));
+    if (is_h16(dtype)) {      // the folded operands, as the UNet's weight loader makes them (unet.hip: wdm_unet_load_param)
+        float *M, *cq, *Wvp, *bvp;
+        WDM_TRY(sc.get<float>((size_t)C * C, &M));
+        WDM_TRY(sc.get<float>((size_t)C, &cq));
+        WDM_TRY(sc.get<float>((size_t)C * C, &Wvp));
+        WDM_TRY(sc.get<float>((size_t)C, &bvp));
+        WDM_TRY(k_attn_fold(p->q_w, p->q_b, p->k_w, p->v_w, p->v_b, p->proj_w, p->proj_b, C, M, cq, Wvp, bvp, c.s));
+        WDM_TRY(pack_conv_w(sc, M, cq, C, C, 1, dtype, c.s, &w.qf));
+        WDM_TRY(pack_conv_w(sc, Wvp, bvp, C, C, 1, dtype, c.s, &w.pf));
+    }
     Tens t0, out;
     WDM_TRY(to_nhwc(sc, c, x, C, H, W, &t0));
     WDM_TRY(run_attn(c, w, t0, &out));

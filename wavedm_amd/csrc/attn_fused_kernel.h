@@ -27,15 +27,23 @@
 namespace wdm {
 
 struct AttnFusedArgs {
-    const void* qk;      // [B][256][2C] bf16
-    const void* vT;      // [B][C][256] bf16
-    void* o;             // [B][256][C] bf16
+    const void* q;       // [B][256][q_ld] token-major queries (bf16 / fp16)
+    const void* k;       // [B][256][k_ld] token-major keys
+    const void* v;       // v_tok = 0: V^T [B][C][256] channel-major; v_tok = 1: V [B][256][v_ld] token-major (read with the transposing LDS load)
+    void* o;             // [B][256][C]
     const float* vbias;  // [C] or nullptr: added to the output rows (the rows of P sum to 1, so P.(V + 1 b^T) = P.V + 1 b^T: V^T is stored without it)
     int B, C;
+    int q_ld, k_ld, v_ld;    // elements per token row
     float alpha;         // C^-1/2
-    unsigned qk_bytes, vt_bytes;
+    unsigned q_bytes, k_bytes, v_bytes;      // extents behind q / k / v (buffer descriptors)
 };
 
+// VTOK = true: V arrives token-major -- the layout every conv / GEMM epilogue writes -- and phase 2 builds its channel-row fragments with ds_read_b64_tr_b16
+// (gfx950's transposing LDS read, as conv_wgrad_kernel.h: the 16 lanes of a group pass the addresses of a [4 keys][16 channels] block and lane i receives
+// column i).  This is what lets the folded AttnBlock (blocks.hip: run_attn) use the normalised input itself as K AND as V: no k / v projections, no V^T tensor.
+// LDS image of a 32-key chunk: row = key (Cp x 2 bytes, a multiple of 256), the 32-byte segment b (16 channels) of row r at segment position
+// (b & ~7) | ((b + f(r)) & 7), f(r) = (r & 3) + 4 ((r >> 3) & 1): the 8 rows one LDS cycle serves (r .. r + 3 and r + 8 .. r + 11, two lane groups)
+// fall on 8 different bank octets.  The k order inside an MFMA is the key order either way: same products, same sums as the V^T form.
 // PROJ = true (C <= 512): proj_out (models/unet.py:189-191: 1x1 conv over the attention output, + bias, + the block's input) runs as a third phase on
 // the workgroup's own 64 queries -- Y^T[co][q] = W_p . O^T over the channels in chunks of 32, W_p streamed through the V^T ring like V^T was, O kept in
 // LDS as the bf16 image the GEMM would have read from HBM -- and leaves through conv_epilogue: the accumulator layout is the conv kernels' (a lane
@@ -53,7 +61,7 @@ struct AttnFusedCfg {
     static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <bool PROJ, typename T_ = __bf16>
+template <bool PROJ, typename T_ = __bf16, bool VTOK = false>
 __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a, const ConvArgs pe) {
     using C = AttnFusedCfg;
     using T = T_;
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         const unsigned long long v = (unsigned long long)p;
         return i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
     };
-    const i32x4 q_qk = make_q(a.qk, a.qk_bytes), q_vt = make_q(a.vT, a.vt_bytes);
+    const i32x4 q_q = make_q(a.q, a.q_bytes), q_k = make_q(a.k, a.k_bytes), q_vt = make_q(a.v, a.v_bytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto dma16 = [&](const i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
         unsigned keep;
@@ -93,12 +101,12 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         const int u = (lane & 7) ^ ((row >> 1) & 7);
         const bool isk = row < N;
         const int tok = isk ? row : qb * QB + (row - N);
-        v1[j] = (unsigned)((((long long)b * N + tok) * (2 * Cc) + (isk ? Cc : 0)) * 2 + u * 16);
+        v1[j] = (unsigned)(((long long)b * N + tok) * (isk ? a.k_ld : a.q_ld) * 2 + u * 16);
     }
     auto issue1 = [&](int step, int buf) __attribute__((always_inline)) {
         const unsigned base = lds0 + buf * C::ST1 + wave * (5 * 1024);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) dma16(q_qk, base + j * 1024, v1[j], step * 128);
+        for (int j = 0; j < 5; ++j) dma16(wave * 5 + j < N / 8 ? q_k : q_q, base + j * 1024, v1[j], step * 128);          // (wave-uniform choice)
     };
     // ---- phase-2 DMA geometry: Cp / 16 pieces of 16 rows x 64 B per 32-key chunk (conv kernel's rotated 64-byte rows); Cp = channels per pass
     const int npass = Cc > C::MAX_CP ? 2 : 1;
@@ -106,17 +114,28 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     const int p2 = Cp / 16;                                            // pieces per chunk (<= 32)
     const bool own_rows = Cp == 512;                                   // every wave fetches exactly the 64 rows it reads (phases 2 and 3): no per-step workgroup barrier there
     const int un2 = (lane & 3) ^ ((lane >> 3) & 2);
+    const int rowb = Cp * 2;                                           // VTOK: bytes per key row of a chunk
     unsigned v2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int piece = wave * 4 + j;
-        const int row = piece * 16 + (lane >> 2);                      // channel of the pass
-        v2[j] = piece < p2 ? (unsigned)((((long long)b * Cc + row) * N) * 2 + un2 * 16) : 0xFFFF0000u;
+        if constexpr (VTOK) {
+            // the chunk image is filled linearly, 1 KB per piece: this lane's 16 bytes are slot s16 of row r; it fetches the unit that belongs there
+            const int off = piece * 1024 + lane * 16;
+            const int r = off / rowb, s16 = (off - r * rowb) >> 4;
+            const int sp = s16 >> 1, f = (r & 3) + 4 * ((r >> 3) & 1);
+            const int bseg = (sp & ~7) | ((sp - f) & 7);
+            v2[j] = piece < p2 ? (unsigned)((((long long)b * N + r) * a.v_ld) * 2 + (bseg * 2 + (s16 & 1)) * 16) : 0xFFFF0000u;
+        } else {
+            const int row = piece * 16 + (lane >> 2);                  // channel of the pass
+            v2[j] = piece < p2 ? (unsigned)((((long long)b * Cc + row) * N) * 2 + un2 * 16) : 0xFFFF0000u;
+        }
     }
     auto issue2 = [&](int pass, int chunk, int buf) __attribute__((always_inline)) {
         const unsigned base = lds0 + C::P_BYTES + buf * C::ST2 + wave * (4 * 1024);
+        const int soff = VTOK ? (chunk * 32 * a.v_ld + pass * Cp) * 2 : pass * Cp * N * 2 + chunk * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(q_vt, base + j * 1024, v2[j], pass * Cp * N * 2 + chunk * 64);
+        for (int j = 0; j < 4; ++j) dma16(q_vt, base + j * 1024, v2[j], soff);
     };
 
     // =========================== phase 1: S^T = K . Q^T ===========================
@@ -225,6 +244,13 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     const int cw = Cp / 8;                                             // channels per wave and pass: 16 ... 64
     const int nfi = cw / 16;                                           // channel fragments per wave (Cp multiple of 128)
     const int va_off = C::P_BYTES + lds_off(wave * cw + (lane & 15), ku);                 // + i * 16 rows * 64 B
+    unsigned va_tr[4];                                                 // VTOK: address of this lane's 8 bytes of the [4 keys][16 channels] block, keys (lane >> 4) * 8 ... + 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int li = lane & 15, g = lane >> 4, bs = wave * (cw >> 4) + i;
+        const int fr = (li >> 2) + 4 * (g & 1);                        // f(row) of row g * 8 + (li >> 2), and of the row four below it
+        va_tr[i] = lds0 + C::P_BYTES + (g * 8 + (li >> 2)) * rowb + ((bs & ~7) | ((bs + fr) & 7)) * 32 + (li & 3) * 8;
+    }
     int pb_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pb_off[j] = (j * 16 + (lane & 15)) * 512;                // + ((chunk*4 + ku) ^ (row & 15)) << 4
@@ -249,16 +275,33 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             // own_rows (Cp = 512): a wave's V^T rows -- the channels it computes -- are exactly the rows it fetched itself (pieces 4 wave ... 4 wave + 3), and the ring
             // slot it overwrites holds only rows it alone reads: its own counted wait is all the synchronisation a step needs.  Only k = 0 needs the workgroup (P)
-            if (k == 0 || !own_rows) __builtin_amdgcn_s_barrier();
+            if (k == 0 || !own_rows || VTOK) __builtin_amdgcn_s_barrier();       // (VTOK: a wave fetches key rows and reads channel columns)
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < N / 32) issue2(pass, k + 2, buf >= 1 ? buf - 1 : 2);
             const char* vb = smem + buf * C::ST2;
             uint4 af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (i < nfi) af[i] = *(const uint4*)(vb + va_off + i * (16 * 64));
             const int pslot = ((k * 4 + ku) ^ prow15) << 4;
+            if constexpr (VTOK) {
+                unsigned long long lo[4], hi[4];
+                const unsigned sb = buf * C::ST2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *(const uint4*)(smem + pb_off[j] + pslot);
+                for (int i = 0; i < 4; ++i)
+                    if (i < nfi) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i]) : "v"(va_tr[i] + sb) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i]) : "v"(va_tr[i] + sb + 4 * rowb) : "memory");
+                    } else { lo[i] = 0; hi[i] = 0; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const uint4*)(smem + pb_off[j] + pslot);
+                // the transposing reads are invisible to the compiler's wait-count bookkeeping: everything has landed behind this wait
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]) :: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = uint4{(unsigned)lo[i], (unsigned)(lo[i] >> 32), (unsigned)hi[i], (unsigned)(hi[i] >> 32)};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < nfi) af[i] = *(const uint4*)(vb + va_off + i * (16 * 64));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const uint4*)(smem + pb_off[j] + pslot);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < nfi)

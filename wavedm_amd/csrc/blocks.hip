@@ -95,7 +95,7 @@ void env_cfg_refresh() {
     auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e ? (e[0] == '0' ? 0 : 1) : dflt; };
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
-    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2);
+    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2); c->attn_fold = num("WDM_ATTN_FOLD", 1);
     c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
@@ -388,10 +388,37 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
     WDM_TRY(materialize_gn(c, w.n, x, nullptr, 0, &hn));
 
     const bool fused = attn_fused_eligible(c.dtype, N, C);
+    if (fused && env_cfg().attn_fold && w.qf.w && w.pf.w && w.qf.cin == C && w.qf.cout == C && w.pf.cin == C && w.pf.cout == C) {
+        // Folded form (k_attn_fold; 16-bit modes): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((M h_i + cq).h_j) and proj_out(P.(Wv h + bv)) = Wvp (P.h) + bvp, so
+        // the normalised input itself is K and V of the core: ONE projection GEMM (q' = M h + cq) instead of three, no V^T tensor, and proj_out runs on Wvp.
+        Tens qf, o;
+        WDM_TRY(run_conv(c, w.qf, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qf, Y_NHWC, nullptr));      // [B][N][C]
+        AttnOperands in;
+        in.q = qf.p; in.q_ld = qf.xs; in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1;
+        if (C <= 512 && env_cfg().attn_fused >= 2 && x.H == 16 && x.W == 16) {
+            ConvArgs a_proj{};
+            Tens odummy;
+            odummy.p = qf.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
+            WDM_TRY(run_conv(c, w.pf, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
+                             next_fin));
+            if (!c.dry) WDM_TRY(launch_attn_fused(in, nullptr, c.B, C, c.s, nullptr, &a_proj, c.dtype));
+            free_tens(c, qf); free_tens(c, hn);
+            return WDM_OK;
+        }
+        WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
+        if (!c.dry) WDM_TRY(launch_attn_fused(in, o.p, c.B, C, c.s, nullptr, nullptr, c.dtype));
+        free_tens(c, qf); free_tens(c, hn);
+        WDM_TRY(run_conv(c, w.pf, MODE_P1, o, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true));
+        free_tens(c, o);
+        return WDM_OK;
+    }
     Tens qk;
     WDM_TRY(run_conv(c, w.qk, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qk, Y_NHWC, nullptr));      // [B][N][2C]
+    AttnOperands in;
+    in.q = qk.p; in.k = (const char*)qk.p + (size_t)C * es; in.q_ld = in.k_ld = qk.xs;
     void* vT = c.ar->alloc((size_t)c.B * C * N * es);                                                               // [B][C][N]
     if (!vT) WDM_FAIL(WDM_ENOMEM, "workspace too small (attention V^T)");
+    in.v = vT;
     // V^T[b] = W_v . h[b]^T as a batched GEMM whose row operand is the weight matrix (shared by the images) and whose per-image "weights" are the
     // tokens: the output rows are channels, so V^T comes out of the ordinary 16-byte-store epilogue instead of the channel-major scalar one
     // (29 -> 18 us).  Its bias moves behind the softmax (attn_fused_kernel.h).  Other shapes: the conv form with the channel-major epilogue.
@@ -425,7 +452,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
         odummy.p = qk.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
         WDM_TRY(run_conv(c, w.proj, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
                          next_fin));
-        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, nullptr, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, &a_proj, c.dtype));
+        if (!c.dry) WDM_TRY(launch_attn_fused(in, nullptr, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, &a_proj, c.dtype));
         c.ar->free(vT);
         free_tens(c, qk);
         return WDM_OK;
@@ -433,7 +460,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
     if (fused) {
         // scores, softmax and P.V in one kernel: S and P never leave the CU (attn_fused_kernel.h)
         WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));
-        if (!c.dry) WDM_TRY(launch_attn_fused(qk.p, vT, o.p, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, nullptr, c.dtype));
+        if (!c.dry) WDM_TRY(launch_attn_fused(in, o.p, c.B, C, c.s, v_as_gemm ? w.v.b : nullptr, nullptr, c.dtype));
         c.ar->free(vT);
     } else {
     float* S = nullptr;

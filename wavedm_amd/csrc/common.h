@@ -133,6 +133,8 @@ struct AttnW {
     NormW n;
     ConvW qk;     // fused: rows [0,C) = q, rows [C,2C) = k
     ConvW v, proj;
+    // 16-bit modes: the folded operands (k_attn_fold): qf = Wk^T Wq with bias Wk^T bq, pf = Wp Wv with bias Wp bv + bp; w == nullptr: not available
+    ConvW qf, pf;
 };
 
 inline int conv_rows_pad(int cout) { return cout <= 16 ? 16 : (int)align_up((size_t)cout, 64); }
@@ -202,12 +204,21 @@ inline bool conv_can_fuse_shortcut(int H, int W, int cin, int cout, int sC0, int
     return (t16 || t8) && cin % 32 == 0 && sC0 % 64 == 0 && (sC0 + sC1) % 64 == 0;
 }
 
-// ---- fused attention core (attn.hip / attn_fused_kernel.h): qk [B][256][2C], vT [B][C][256] -> o [B][256][C], bf16
+// ---- fused attention core (attn.hip / attn_fused_kernel.h): q, k [B][256][ld] token-major, v = V^T [B][C][256] or (v_tok) V [B][256][v_ld] -> o [B][256][C], 16-bit
 bool attn_fused_eligible(int dtype, int N, int C);
-// vbias != nullptr: vT was computed without the v bias, which is added to the output instead
+struct AttnOperands {
+    const void* q = nullptr; const void* k = nullptr; const void* v = nullptr;
+    int q_ld = 0, k_ld = 0, v_ld = 0;      // elements per token row (v_ld: token-major V only)
+    int v_tok = 0;
+};
+// vbias != nullptr: V was computed without the v bias, which is added to the output instead
 // proj != nullptr (C <= 512): proj_out fused in as a third phase; *proj = the 1x1 conv's arguments as run_conv builds them (weights, bias, residual, output,
 // statistics); o is then unused
-int launch_attn_fused(const void* qk, const void* vT, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr, const ConvArgs* proj = nullptr, int dtype = WDM_BF16);
+int launch_attn_fused(const AttnOperands& in, void* o, int B, int C, hipStream_t s, const float* vbias = nullptr, const ConvArgs* proj = nullptr, int dtype = WDM_BF16);
+// AttnBlock operand folding (elementwise.hip), fp32 in / out, fp64 sums: M = Wk^T Wq, cq = Wk^T bq (scores: (Wq h_i + bq).(Wk h_j + bk) = (M h_i + cq).h_j + terms constant
+// in j, which the softmax cancels); Wvp = Wp Wv, bvp = Wp bv + bp (proj_out(P.(Wv h + bv)) = Wvp (P.h) + bvp: the rows of P sum to one)        (models/unet.py:176-191)
+int k_attn_fold(const float* wq, const float* bq, const float* wk, const float* wv, const float* bv, const float* wp, const float* bp, int C, float* M, float* cq, float* Wvp,
+                float* bvp, hipStream_t s);
 
 // ---- experiment switches (environment), read ONCE -- at first use or when wdm_env_refresh() is called (tests and A/B harnesses that change the
 // environment inside a running process call it); no launch path calls getenv.  Defaults are the measured best.
@@ -221,6 +232,7 @@ struct EnvCfg {
     int gn_inline = 1;    // WDM_GN_INLINE=0: a gn_finalize launch for every conv with the GroupNorm prologue; 1 (default): finalised in the consumer's own prologue where the producer
                           // left group partials (maps up to 32 x 32, single input: gn_inline.h); 2: everything else finalised by the PRODUCER's last workgroups (gn_arrive.h: built
                           // in round 4, bit-identical to the launches, 3.6 % SLOWER end to end -- one workgroup per image reduces what 2 048 waves of gn_finalize do side by side)
+    int attn_fold = 1;    // WDM_ATTN_FOLD=0: the AttnBlock keeps its k and v projections (16-bit modes; blocks.hip: run_attn); 1: folded into q and proj_out at load time
     int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: the batched-GEMM form of the weight gradient everywhere, n images per group (0: direct kernel for 3x3 stride-1 layers, training)

@@ -796,4 +796,49 @@ int k_copy_f32(const float* src, float* dst, long long n, hipStream_t s) {
     return WDM_OK;
 }
 
+// ---- AttnBlock operand folding (set-up path: runs when a parameter of an AttnBlock is loaded; common.h: k_attn_fold) -------------------------------------
+// out[r][c] = sum_o A(o, r) B[o][c]  (TA: A^T B)   |   sum_m A[r][m] B[m][c]  (A B); C x C fp32 matrices, fp64 sums in a fixed (ascending) order
+template <bool TA>
+__global__ __launch_bounds__(256) void fold_mm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ out, int C) {
+    __shared__ float sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r = blockIdx.y * 16 + ty, c = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < C; k0 += 16) {
+        // sa[kk][rr] = A(k0 + kk, r0 + rr) (TA) or A[r0 + rr][k0 + kk]
+        const int ar = blockIdx.y * 16 + (TA ? tx : ty), ak = k0 + (TA ? ty : tx);
+        sa[TA ? ty : tx][TA ? tx : ty] = (ar < C && ak < C) ? (TA ? A[(size_t)ak * C + ar] : A[(size_t)ar * C + ak]) : 0.f;
+        sb[ty][tx] = (k0 + ty < C && c < C) ? Bm[(size_t)(k0 + ty) * C + c] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc += (double)sa[kk][ty] * (double)sb[kk][tx];
+        __syncthreads();
+    }
+    if (r < C && c < C) out[(size_t)r * C + c] = (float)acc;
+}
+// out[r] = sum_o A(o, r) x[o] (TA) | sum_m A[r][m] x[m], + add[r] when given
+template <bool TA>
+__global__ __launch_bounds__(64) void fold_mv_kernel(const float* __restrict__ A, const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ out, int C) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int k = lane; k < C; k += 64) acc += (double)(TA ? A[(size_t)k * C + r] : A[(size_t)r * C + k]) * (double)x[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) out[r] = (float)(acc + (add ? (double)add[r] : 0.0));
+}
+int k_attn_fold(const float* wq, const float* bq, const float* wk, const float* wv, const float* bv, const float* wp, const float* bp, int C, float* M, float* cq, float* Wvp,
+                float* bvp, hipStream_t s) {
+    const dim3 g((C + 15) / 16, (C + 15) / 16);
+    if (M) {
+        hipLaunchKernelGGL(fold_mm_kernel<true>, g, dim3(256), 0, s, wk, wq, M, C);                          // M[c'][c] = sum_o Wk[o][c'] Wq[o][c]
+        hipLaunchKernelGGL(fold_mv_kernel<true>, dim3(C), dim3(64), 0, s, wk, bq, (const float*)nullptr, cq, C);      // cq[c'] = sum_o Wk[o][c'] bq[o]
+    }
+    if (Wvp) {
+        hipLaunchKernelGGL(fold_mm_kernel<false>, g, dim3(256), 0, s, wp, wv, Wvp, C);                       // Wvp[o][c] = sum_m Wp[o][m] Wv[m][c]
+        hipLaunchKernelGGL(fold_mv_kernel<false>, dim3(C), dim3(64), 0, s, wp, bv, bp, bvp, C);              // bvp[o] = sum_m Wp[o][m] bv[m] + bp[o]
+    }
+    WDM_HIP(hipGetLastError());
+    return WDM_OK;
+}
+
 }  // namespace wdm

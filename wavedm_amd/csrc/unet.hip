@@ -31,13 +31,18 @@ struct ParamSlot {
     size_t sm_off = 0;       // PK_CONV of a bf16 3x3 conv: second destination, the slab-major copy (k_pack_conv_sm); 0 = none
     size_t up4_off = 0;      // PK_CONV of an Upsample conv (bf16): second destination, the 16 sub-pixel taps (k_pack_up4); 0 = none
     bool loaded = false;
+    int fold = -1, fold_role = -1;   // tensor of an AttnBlock whose folded operands are rebuilt when it is loaded (16-bit modes): index into wdm_unet::folds, FR_* role
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 };
 
 struct ConvD { size_t w_off, b_off; int cin, cout, k, rows_pad; size_t up4_off, sm_off; };
 struct NormD { size_t g_off, b_off; int c; };
 struct ResD { int cin, cout; NormD n1, n2; ConvD c1, c2, nin; bool has_nin; int temb_row; };
-struct AttnD { int c; NormD n; ConvD qk, v, proj; };
+struct AttnD { int c; NormD n; ConvD qk, v, proj, qf, pf; int fold; };
+// folded AttnBlock operands (common.h: k_attn_fold): the fp32 originals of the four matrices are kept ([Wq | Wk | Wv | Wp] at stage_off) so that any one tensor can be
+// reloaded; the biases' fp32 copies are the ones the unfolded convs use
+enum { FR_QW = 0, FR_KW, FR_VW, FR_PW, FR_QB, FR_VB, FR_PB, FR_N };
+struct FoldD { int c; size_t stage_off; ConvD qk, v, proj, qf, pf; int slot[FR_N]; };
 
 }  // namespace
 
@@ -48,6 +53,8 @@ struct wdm_unet {
     std::map<std::string, int> index;
     size_t packed_bytes = 0;
     size_t range_flag_off = 0;      // WDM_F16 only
+    std::vector<FoldD> folds;       // 16-bit modes: one per AttnBlock
+    size_t fold_tmp_floats = 0, fold_tmp_off = 0;
     char* packed = nullptr;
     bool all_loaded = false;
     int temb_ch = 0, temb_rows = 0;   // rows of the concatenated temb_proj matrix
@@ -129,6 +136,25 @@ struct wdm_unet {
         a.qk = qk;
         a.v = add_conv(name + ".v", c, c, 1);
         a.proj = add_conv(name + ".proj_out", c, c, 1);
+        a.fold = -1;
+        if (is_h16(cfg.dtype)) {
+            // the folded operands the fused core runs on (blocks.hip: run_attn), rebuilt by wdm_unet_load_param whenever one of the seven tensors behind them arrives
+            FoldD f{};
+            f.c = c;
+            auto plain = [&](ConvD& d) { d = ConvD{}; d.cin = c; d.cout = c; d.k = 1; d.rows_pad = conv_rows_pad(c); d.w_off = take(conv_packed_bytes(c, c, 1, cfg.dtype)); d.b_off = take((size_t)c * 4); };
+            plain(a.qf); plain(a.pf);
+            f.stage_off = take((size_t)4 * c * c * 4);
+            f.qk = a.qk; f.v = a.v; f.proj = a.proj; f.qf = a.qf; f.pf = a.pf;
+            const char* names[FR_N] = {".q.weight", ".k.weight", ".v.weight", ".proj_out.weight", ".q.bias", ".v.bias", ".proj_out.bias"};
+            for (int r = 0; r < FR_N; ++r) {
+                f.slot[r] = index.at(name + names[r]);
+                params[f.slot[r]].fold = (int)folds.size();
+                params[f.slot[r]].fold_role = r;
+            }
+            fold_tmp_floats = std::max(fold_tmp_floats, (size_t)c * c);
+            a.fold = (int)folds.size();
+            folds.push_back(f);
+        }
         return a;
     }
 
@@ -145,8 +171,10 @@ struct wdm_unet {
         r.temb_per_image = n_t > 1;
         return r;
     }
-    AttnW aw(const AttnD& d) const { AttnW a; a.c = d.c; a.n = nw(d.n); a.qk = cw(d.qk); a.v = cw(d.v); a.proj = cw(d.proj); return a; }
+    AttnW aw(const AttnD& d) const { AttnW a; a.c = d.c; a.n = nw(d.n); a.qk = cw(d.qk); a.v = cw(d.v); a.proj = cw(d.proj); if (d.fold >= 0) { a.qf = cw(d.qf); a.pf = cw(d.pf); } return a; }
 
+    int refold(const ParamSlot& p, const float* dev_src, hipStream_t s);
+    int check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s);
     int forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out, const float* temb_pre = nullptr);
     int temb_table(Ctx& c, const float* t, int n_t, float* temb_all);
 };
@@ -209,6 +237,7 @@ int wdm_unet::build() {
     conv_out = add_conv("conv_out", block_in, cfg.out_ch, 3);
 
     // all temb_proj Linear layers concatenated into one [sum(cout)][temb_ch] fp32 matrix: one GEMV launch per step
+    if (fold_tmp_floats) fold_tmp_off = take(fold_tmp_floats * 4);      // one C x C fp32 product of the AttnBlock folding, before it is packed
     if (cfg.dtype == WDM_F16) range_flag_off = take(256);      // device int the weight loader's fp16 range check writes (wdm_unet_load_param)
     temb_w_off = take((size_t)temb_rows * temb_ch * 4);
     temb_b_off = take((size_t)temb_rows * 4);
@@ -219,6 +248,43 @@ int wdm_unet::build() {
         row += e.second;
     }
     return WDM_OK;
+}
+
+// fp16 operands: a weight outside +-65504 (or not finite) would become inf in the packed matrix -- refuse it, loudly.  The one place the weight loader waits for the
+// stream (set-up path; the sampling path never does)
+int wdm_unet::check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s) {
+    int* flag = (int*)(packed + range_flag_off);
+    int host_flag = 0;
+    WDM_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+    WDM_TRY(k_flag_out_of_range(dev, n, 65504.0f, flag, s));
+    WDM_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    WDM_HIP(hipStreamSynchronize(s));
+    if (host_flag) WDM_FAIL(WDM_EINVAL, "parameter '%s': a value lies outside the fp16 range (|w| <= 65504, finite) -- use WDM_BF16 or WDM_F32X3 for this checkpoint", what);
+    return WDM_OK;
+}
+
+// A tensor of an AttnBlock arrived: keep the matrix's fp32 original and rebuild the folded operand it belongs to once all of that operand's tensors are there
+// (q.weight, k.weight, q.bias -> qf;  v.weight, proj_out.weight, v.bias, proj_out.bias -> pf;  k.bias cancels in the softmax)
+int wdm_unet::refold(const ParamSlot& p, const float* dev_src, hipStream_t s) {
+    const FoldD& f = folds[p.fold];
+    const size_t cc = (size_t)f.c * f.c;
+    float* stage = (float*)(packed + f.stage_off);
+    if (p.fold_role <= FR_PW) WDM_TRY(k_copy_f32(dev_src, stage + p.fold_role * cc, (long long)cc, s));
+    const bool qk_side = p.fold_role == FR_QW || p.fold_role == FR_KW || p.fold_role == FR_QB;
+    auto have = [&](std::initializer_list<int> roles) { for (int r : roles) if (!params[f.slot[r]].loaded) return false; return true; };
+    float* tmp = (float*)(packed + fold_tmp_off);
+    const ConvD& dst = qk_side ? f.qf : f.pf;
+    if (qk_side) {
+        if (!have({FR_QW, FR_KW, FR_QB})) return WDM_OK;
+        WDM_TRY(k_attn_fold(stage + FR_QW * cc, (const float*)(packed + f.qk.b_off), stage + FR_KW * cc, nullptr, nullptr, nullptr, nullptr, f.c, tmp, (float*)(packed + dst.b_off), nullptr,
+                            nullptr, s));
+    } else {
+        if (!have({FR_VW, FR_PW, FR_VB, FR_PB})) return WDM_OK;
+        WDM_TRY(k_attn_fold(nullptr, nullptr, nullptr, stage + FR_VW * cc, (const float*)(packed + f.v.b_off), stage + FR_PW * cc, (const float*)(packed + f.proj.b_off), f.c, nullptr, nullptr,
+                            tmp, (float*)(packed + dst.b_off), s));
+    }
+    if (cfg.dtype == WDM_F16) WDM_TRY(check_f16_range(tmp, (int64_t)cc, qk_side ? "Wk^T Wq of an AttnBlock" : "Wp Wv of an AttnBlock", s));
+    return k_pack_conv(tmp, f.c, f.c, 1, packed + dst.w_off, dst.rows_pad, 0, 1, cfg.dtype, s);
 }
 
 int wdm_unet::temb_table(Ctx& c, const float* t, int n_t, float* temb_all) {
@@ -439,17 +505,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     hipStream_t s = (hipStream_t)stream;
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
-        if (u->cfg.dtype == WDM_F16) {
-            // fp16 operands: a weight outside +-65504 (or not finite) would become inf in the packed matrix -- refuse it here, loudly.  The one place this
-            // entry point waits for the stream (set-up path; the sampling path never does)
-            int* flag = (int*)(u->packed + u->range_flag_off);
-            int host_flag = 0;
-            WDM_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-            WDM_TRY(k_flag_out_of_range(dev_src, numel, 65504.0f, flag, s));
-            WDM_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-            WDM_HIP(hipStreamSynchronize(s));
-            if (host_flag) WDM_FAIL(WDM_EINVAL, "parameter '%s': a value lies outside the fp16 range (|w| <= 65504, finite) -- use WDM_BF16 or WDM_F32X3 for this checkpoint", name);
-        }
+        if (u->cfg.dtype == WDM_F16) WDM_TRY(u->check_f16_range(dev_src, numel, name, s));
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
         if (p.sm_off) WDM_TRY(k_pack_conv_sm(dev_src, cout, cin, u->packed + p.sm_off, p.rows_total, s, u->cfg.dtype));
         if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s, u->cfg.dtype));
@@ -457,6 +513,7 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
     }
     p.loaded = true;
+    if (p.fold >= 0) WDM_TRY(u->refold(p, dev_src, s));
     bool all = true;
     for (auto& q : u->params) all = all && q.loaded;
     u->all_loaded = all;
