@@ -2,7 +2,7 @@
 # K-split 8 x 8 kernel (conv_dma8k_kernel.h) against the shipped 128 x 48 tile, stand-alone: warm, cold weights, with a fused shortcut, and the ablations
 # usage (GPU box): bash scripts/dma8k_bench.sh > gpurun_out/dma8k_bench.log 2>&1
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-B="hipcc --offload-arch=gfx950 -O3 -std=c++17 -I wavedm_amd/csrc -I include tools/dma8k_bench.hip"
+B="hipcc --offload-arch=gfx950 -O3 -std=c++17 -I wavedm_amd/csrc -I include -I tools tools/dma8k_bench.hip"
 $B -o /tmp/d8k || exit 1
 for shape in "64 768 768" "64 1536 768" "64 1280 768" "8 768 768"; do
   echo "== $shape warm"; /tmp/d8k $shape

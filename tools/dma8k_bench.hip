@@ -1,6 +1,6 @@
 // conv_dma8k_kernel.h (K-split 128 x 96 tile, eight waves) against conv_dma8_kernel.h (128 x 48, four waves, two workgroups per CU) on one 8 x 8 layer:
 // outputs compared (the two differ in summation order only), both timed warm and with the weights cold (COLD=<n> copies in rotation, as inside the UNet).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWDM_D8KABL=<m> -DWDM_D8ABL=<m>] -I wavedm_amd/csrc -I include tools/dma8k_bench.hip -o /tmp/dma8k_bench
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWDM_D8KABL=<m> -DWDM_D8ABL=<m>] -I wavedm_amd/csrc -I include -I tools tools/dma8k_bench.hip -o /tmp/dma8k_bench
 // run:   [SC=<shortcut channels>] [COLD=24] [GN=4] /tmp/dma8k_bench B Cin Cout
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "conv_dma8_kernel.h"
-#include "conv_dma8k_kernel.h"
+#include "experiments/conv_dma8k_kernel.h"
 using namespace wdm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 

@@ -96,7 +96,7 @@ void env_cfg_refresh() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
     c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2); c->attn_fold = num("WDM_ATTN_FOLD", 1);
-    c->up4 = flag("WDM_UP4", 1); c->dma8k = num("WDM_DMA8K", 0); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
+    c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
 }

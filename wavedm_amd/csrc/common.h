@@ -234,7 +234,6 @@ struct EnvCfg {
                           // in round 4, bit-identical to the launches, 3.6 % SLOWER end to end -- one workgroup per image reduces what 2 048 waves of gn_finalize do side by side)
     int attn_fold = 1;    // WDM_ATTN_FOLD=0: the AttnBlock keeps its k and v projections (16-bit modes; blocks.hip: run_attn); 1: folded into q and proj_out at load time
     int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
-    int dma8k = 0;        // WDM_DMA8K=1: 3x3 convs of the 8 x 8 maps with Cout % 96 == 0 and an even number of 32-channel slabs on the K-split 128 x 96 tile (conv_dma8k_kernel.h)
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: the batched-GEMM form of the weight gradient everywhere, n images per group (0: direct kernel for 3x3 stride-1 layers, training)
 };

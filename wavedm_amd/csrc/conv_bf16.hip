@@ -6,6 +6,5 @@
 #include "conv_dma256_kernel.h"
 #include "conv_up4_kernel.h"
 #include "conv_dma8_kernel.h"
-#include "conv_dma8k_kernel.h"
 #include "conv_s2_kernel.h"
 #include "conv_dispatch.inc"
