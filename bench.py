@@ -33,6 +33,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 # tools/mfma_power_ubench.hip, profiles/r05_mfma_power_ubench.log -- 1 845 TFLOP/s against 2 476 on all-zero operands: the power limit, not the pipe).  `roofline.peak`
 # stays the nominal figure the contract names; `roofline.sustained` prices the same achieved rate against this one.
 MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS = 1845.0
+# ... and when every MFMA's operands are fresh ds_read_b128 fragments of random data in LDS (0.375-0.5 reads per MFMA, 8-16 waves per CU, no barriers, no DMA, no
+# global traffic: the same tool's LDS-fed mode, profiles/r05_mfma_power_ldsfed.log -- 1 420 ... 1 470 TFLOP/s; 1 950 ... 2 165 on zeros): the ceiling of ANY LDS-fed
+# 16-bit MFMA loop on this board, which is what a convolution kernel is.
+MFMA_16BIT_LDS_FED_RANDOM_TFLOPS = 1450.0
 
 
 def log(*a):
@@ -259,7 +263,10 @@ def main():
         if args.dtype in ("bf16", "f16"):
             roofline["sustained"] = {"peak": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, 4),
                                      "what": "register-resident 16x16x32 MFMA loop on random 16-bit operands, measured on this board class (power-limited; 2476 on zeros): "
-                                             "profiles/r05_mfma_power_ubench.log"}
+                                             "profiles/r05_mfma_power_ubench.log",
+                                     "lds_fed": {"peak": MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, 4),
+                                                 "what": "the same loop with every operand a fresh ds_read_b128 fragment of random data in LDS (0.375-0.5 reads per MFMA, "
+                                                         "no barriers / DMA / global traffic): 1420-1470 measured, profiles/r05_mfma_power_ldsfed.log"}}
         # Since round 3 the 3x3 stride-1 convs of the 16-pixel-multiple maps -- ONE kernel name until round 2 -- run as three tilings / schedules of the
         # same LDS-DMA design (256 x 128 persistent on the 64 x 64 maps, 256 x 128 on 16 x 16, 256 x 256 on 32 x 32), so "the dominant kernel" above is
         # the largest of the three; the family figure is the like-for-like successor of round 2's single-kernel number.

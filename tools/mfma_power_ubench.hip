@@ -1,5 +1,6 @@
 // Which MFMA shape does the board sustain better on RANDOM 16-bit operands (power-limited regime)?  (not part of the library)
 // Every CU: 8 waves, each 4096 x [64 MFMA-units of work] from registers holding random bf16 / fp16 data; no memory traffic in the loop.
+//   (round 5, second half: + an LDS-fed mode, kl<NA, NB>: the same MFMA stream with every operand a fresh ds_read_b128 fragment -- the roof of an LDS-fed kernel)
 //   mode 0: v_mfma_f32_16x16x32_bf16   1: v_mfma_f32_32x32x16_bf16   2: v_mfma_f32_16x16x32_f16   3: v_mfma_f32_32x32x16_f16     ZERO=1: all-zero operands
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_power_ubench.hip -o tools/abl_mfma_power
 #include <hip/hip_runtime.h>
@@ -55,6 +56,70 @@ __global__ __launch_bounds__(512, 2) void k(const uint4* src, int iters, float* 
     if (r == 123.456f) sink[t] = r;
 }
 
+
+// LDS-fed variant (round 5): the same MFMA stream, but every iteration's operands are fresh ds_read_b128 fragments of random data in LDS (64 KB per workgroup, two
+// workgroups per CU; contiguous 1 KB per wave-instruction: conflict-free) -- NA + NB fragment reads for NA x NB MFMAs, the next iteration's reads issued before this
+// iteration's MFMAs.  No barriers, no global traffic: what an LDS-fed 16x16x32 loop can sustain at 0.5 (4 + 4) or 0.375 (4 + 8) reads per MFMA.
+template <int NA, int NB, bool F16>
+__global__ __launch_bounds__(512, 2) void kl(const uint4* src, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += 512) ((uint4*)smem)[i] = src[(blockIdx.x * 4096 + i) & 0xFFFFF];
+    __syncthreads();
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 a[NA], b[NB], an[NA], bn[NB];
+    auto ld = [&](int it, uint4 (&x)[NA], uint4 (&y)[NB]) __attribute__((always_inline)) {
+        const int base = (it * (NA + NB) + wave * 5) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) x[i] = *(const uint4*)(smem + ((base + i * 1024) & 0xFFFF));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) y[j] = *(const uint4*)(smem + ((base + (NA + j) * 1024) & 0xFFFF));
+    };
+    ld(0, a, b);
+    for (int it = 0; it < iters; ++it) {
+        ld(it + 1, an, bn);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[j] = bn[j];
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r += acc[i][j][0] + acc[i][j][3];
+    if (r == 123.456f) sink[blockIdx.x * 512 + tid] = r;
+}
+template <int NA, int NB, bool F16>
+static void run_l(const uint4* src, const char* what) {
+    const int iters = 16384 / (NA * NB) * 4, grid = 256 * 2;
+    CK(hipFuncSetAttribute((const void*)kl<NA, NB, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((kl<NA, NB, F16>), dim3(grid), dim3(512), 65536, 0, src, iters, (float*)nullptr);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f, sum = 0.f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((kl<NA, NB, F16>), dim3(grid), dim3(512), 65536, 0, src, iters, (float*)nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best; sum += ms;
+    }
+    const double flop = (double)grid * 8 * iters * (NA * NB) * 2.0 * 16 * 16 * 32;
+    printf("%-44s best %7.3f ms  %6.0f TFLOP/s   mean %7.3f ms %6.0f TFLOP/s\n", what, best, flop / best / 1e9, sum / 5, flop / (sum / 5) / 1e9);
+}
+
 template <int MODE>
 static void run(const uint4* src, const char* what) {
     const int iters = 4096, grid = 256 * 2;
@@ -87,6 +152,10 @@ int main() {
         run<1>(src, "32x32x16 bf16");
         run<2>(src, "16x16x32 f16");
         run<3>(src, "32x32x16 f16");
+        run_l<4, 4, false>(src, "LDS-fed 16x16x32 bf16, 0.50 reads per MFMA");
+        run_l<4, 8, false>(src, "LDS-fed 16x16x32 bf16, 0.375 reads per MFMA");
+        run_l<4, 4, true>(src, "LDS-fed 16x16x32 f16, 0.50 reads per MFMA");
+        run_l<4, 8, true>(src, "LDS-fed 16x16x32 f16, 0.375 reads per MFMA");
     }
     return 0;
 }
