@@ -71,8 +71,10 @@ def _short(name: str) -> str:
     if m:
         return f"convdma8_3x3s1_t8x8x2_bn{m.group(1)}w4_bf16"
     if "attn_fused_kernel" in name:
-        m = re.search(r"attn_fused_kernelILb\dE(?:DF16b|DF16_)Lb(\d)E", name)      # <PROJ, T, VTOK>: "t" = token-major V (the folded AttnBlock)
-        return "attn_fused_n256t_bf16" if m and m.group(1) == "1" else "attn_fused_n256_bf16"
+        m = re.search(r"attn_fused_kernelILb\dE(?:DF16b|DF16_)Lb(\d)E(?:Lb(\d)E)?", name)      # <PROJ, T, VTOK, QPROJ>: "t" = token-major V (the folded AttnBlock), "q" = query projection inside
+        if m and m.group(1) == "1":
+            return "attn_fused_n256tq_bf16" if m.group(2) == "1" else "attn_fused_n256t_bf16"
+        return "attn_fused_n256_bf16"
     m = re.search(r"conv_wgrad_kernelILb(\d)E", name)
     if m:                                            # training: the direct weight gradient, <true> = 8 x 8 maps
         return "conv_wgrad_8x8_bf16" if m.group(1) == "1" else "conv_wgrad_bf16"

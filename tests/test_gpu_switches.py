@@ -98,6 +98,33 @@ def test_proj_out_fused_into_the_attention_core_gives_the_same_bits(gu):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_query_projection_inside_the_attention_core_gives_the_same_bits(gu, dtype):
+    """attn_fused_kernel<PROJ, T, VTOK, QPROJ> (WDM_ATTN_FUSED=3, the default): the folded block's one remaining GEMM, q' = (Wk^T Wq) h + Wk^T bq, as phase 0 of the core on the
+    workgroup's own 64 queries == the stand-alone GEMM (WDM_ATTN_FUSED=2): the same MFMA sequence per output, the same single rounding to 16 bits -- and one launch per AttnBlock."""
+    from wavedm_amd import _lib
+    for C, B in ((512, 5), (256, 3), (128, 9), (384, 2)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("at", shapes)
+        x = gu.seeded((B, C, 16, 16), 19)
+
+        def run():
+            _lib.prof_enable(True)
+            out = gu.attn(sd, "at", x, dtype)
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report()]
+            _lib.prof_enable(False)
+            return out, names
+        y, k3 = run()
+        y2, k2 = _with({"WDM_ATTN_FUSED": "2"}, run)
+        assert any(n.startswith("attn_fused_n256tq") for n in k3) and not any(n.startswith("gemm_1x1") or n.startswith("conv_1x1") for n in k3), k3
+        assert any(n.startswith("gemm_1x1") or n.startswith("conv_1x1") for n in k2) and not any("n256tq" in n for n in k2), k2
+        assert torch.isfinite(y).all() and torch.equal(y, y2), C
+        assert rel_linf(y, gu.attn(sd, "at", x, "f32")) <= gu.TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_attention_block_on_folded_operands(gu, dtype):
     """16-bit modes (blocks.hip: run_attn): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((Wk^T Wq h_i + Wk^T bq).h_j) and proj_out(P.(Wv h + bv)) = (Wp Wv)(P.h) + Wp bv + bp, so
     the block runs ONE projection GEMM and the fused core with the normalised input as K and as (token-major, transposing-read) V.  WDM_ATTN_FOLD=0 keeps the k / v
@@ -122,7 +149,7 @@ def test_attention_block_on_folded_operands(gu, dtype):
         e1, e0 = rel_linf(y, ref), rel_linf(y0, ref)
         print(f"attn {dtype} C={C}: folded {e1:.2e}  k / v projections {e0:.2e}")
         assert torch.isfinite(y).all() and e1 <= gu.TOL[dtype] and e0 <= gu.TOL[dtype]
-        assert any(n.startswith("attn_fused_n256t_") for n in k1) and not any(n.startswith("attn_fused_n256t_") for n in k0), (k1, k0)
+        assert any(n.startswith("attn_fused_n256t") for n in k1) and not any(n.startswith("attn_fused_n256t") for n in k0), (k1, k0)      # ("n256tq": with the query projection inside)
         assert len(k1) == len(k0) - 1, (k1, k0)                      # q' instead of q|k and V^T
         assert torch.equal(y, run()[0])
 

@@ -16,8 +16,11 @@ bool attn_fused_eligible(int dtype, int N, int C) {
 template <typename T, bool VTOK>
 static int launch_attn_fused_t(const AttnOperands& in, void* o, int B, int C, hipStream_t s, const float* vbias, const ConvArgs* proj) {
     using Cf = AttnFusedCfg;
-    if (!in.q || !in.k || !in.v || (!o && !proj) || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
-    if (in.q_ld < C || in.k_ld < C || (in.q_ld | in.k_ld) % 8 || (VTOK && (in.v_ld < C || in.v_ld % 8))) WDM_FAIL(WDM_EINVAL, "attn(fused): row strides must be multiples of 8 elements >= C");
+    const bool qproj = in.qw != nullptr;
+    if ((!in.q && !qproj) || !in.k || !in.v || (!o && !proj) || B <= 0) WDM_FAIL(WDM_EINVAL, "attn(fused): bad argument");
+    if (qproj && (!VTOK || !proj || in.q || in.k != in.v || in.qw_ld < C || in.qw_ld % 8 || in.qw_bytes == 0 || in.qw_bytes >= 4294901760.0))
+        WDM_FAIL(WDM_EINVAL, "attn(fused): the in-kernel query projection needs the folded block's operands (K = V = the normalised input, proj_out fused)");
+    if ((!qproj && in.q_ld < C) || in.k_ld < C || ((qproj ? 0 : in.q_ld) | in.k_ld) % 8 || (VTOK && (in.v_ld < C || in.v_ld % 8))) WDM_FAIL(WDM_EINVAL, "attn(fused): row strides must be multiples of 8 elements >= C");
     if (proj && (C > 512 || proj->Cout != C || proj->Cin != C || proj->Hout != 16 || proj->Wout != 16 || proj->B != B || !proj->w || proj->w_bytes == 0 || proj->y_mode != Y_NHWC ||
                  proj->temb || proj->m_valid || proj->up4 || (proj->stats && proj->stats_nslab != 4)))
         WDM_FAIL(WDM_EINVAL, "attn(fused): proj_out epilogue arguments do not describe a C = %d 1x1 conv on 16 x 16 maps", C);
@@ -28,26 +31,29 @@ static int launch_attn_fused_t(const AttnOperands& in, void* o, int B, int C, hi
     a.q_ld = in.q_ld; a.k_ld = in.k_ld; a.v_ld = in.v_ld;
     a.alpha = (float)std::pow((double)C, -0.5);
     // extents behind the three pointers (q and k may be column ranges of one tensor: the last row ends C elements behind its start)
-    a.q_bytes = (unsigned)(qb - (in.q_ld - C) * 2.0); a.k_bytes = (unsigned)(kb - (in.k_ld - C) * 2.0); a.v_bytes = (unsigned)(VTOK ? vb - (in.v_ld - C) * 2.0 : vb);
+    a.qw = in.qw; a.qbias = in.qbias; a.qw_ld = in.qw_ld; a.qw_bytes = (unsigned)in.qw_bytes;
+    a.q_bytes = qproj ? 0u : (unsigned)(qb - (in.q_ld - C) * 2.0); a.k_bytes = (unsigned)(kb - (in.k_ld - C) * 2.0); a.v_bytes = (unsigned)(VTOK ? vb - (in.v_ld - C) * 2.0 : vb);
     static std::atomic<unsigned> devs{0};
     int dev = 0;
     WDM_HIP(hipGetDevice(&dev));
     if (!(devs.load() & (1u << (dev & 31)))) {
         WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<false, T, VTOK>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
         WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<true, T, VTOK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (VTOK) WDM_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<true, T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         devs.fetch_or(1u << (dev & 31));
     }
     const bool prof = prof_enabled();
     if (prof) {
         char name[96];
-        snprintf(name, sizeof(name), "attn_fused_n256%s_%s|16x16 C=%d%s", VTOK ? "t" : "", std::is_same<T, f16_t>::value ? "f16" : "bf16", C, proj ? " +proj" : "");
-        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
-                   (double)B * Cf::N * C * 2.0 * (proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0));
+        snprintf(name, sizeof(name), "attn_fused_n256%s%s_%s|16x16 C=%d%s%s", VTOK ? "t" : "", qproj ? "q" : "", std::is_same<T, f16_t>::value ? "f16" : "bf16", C, qproj ? " qproj+" : "", proj ? " +proj" : "");
+        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0) + (qproj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
+                   (double)B * Cf::N * C * 2.0 * (qproj ? 3.0 : proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0) + (qproj ? (double)C * C * 2.0 : 0.0));
     }
     ConvArgs pe{};
     if (proj) pe = *proj;
     pe.fin_total = AttnFusedCfg::N / AttnFusedCfg::QB;          // gn_arrive.h: the image's query blocks
-    if (proj) hipLaunchKernelGGL((attn_fused_kernel<true, T, VTOK>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
+    if (qproj) { if constexpr (VTOK) hipLaunchKernelGGL((attn_fused_kernel<true, T, true, true>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe); }
+    else if (proj) hipLaunchKernelGGL((attn_fused_kernel<true, T, VTOK>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
     else hipLaunchKernelGGL((attn_fused_kernel<false, T, VTOK>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
     if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());

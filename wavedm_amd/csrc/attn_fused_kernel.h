@@ -36,6 +36,12 @@ struct AttnFusedArgs {
     int q_ld, k_ld, v_ld;    // elements per token row
     float alpha;         // C^-1/2
     unsigned q_bytes, k_bytes, v_bytes;      // extents behind q / k / v (buffer descriptors)
+    // QPROJ (round 5, folded AttnBlock only): the query projection q' = Mq . h + cq runs inside the kernel as phase 0 -- q is then unused, the workgroup's 64 query rows
+    // are rows of k (the normalised input itself)
+    const void* qw;      // [C][qw_ld] 16-bit: Mq = Wk^T Wq (rows = output channels)
+    const float* qbias;  // [C]: cq = Wk^T bq
+    int qw_ld;
+    unsigned qw_bytes;
 };
 
 // VTOK = true: V arrives token-major -- the layout every conv / GEMM epilogue writes -- and phase 2 builds its channel-row fragments with ds_read_b64_tr_b16
@@ -49,6 +55,11 @@ struct AttnFusedArgs {
 // LDS as the bf16 image the GEMM would have read from HBM -- and leaves through conv_epilogue: the accumulator layout is the conv kernels' (a lane
 // holds 4 consecutive output channels of one query = pixel), a query block is one 64-row statistics slab of the 16 x 16 map.  Same MFMA sequence per
 // output and same epilogue as the stand-alone GEMM, hence the same bits; one 22 us launch and the O round trip through HBM gone per AttnBlock.
+// QPROJ = true (round 5; PROJ and VTOK, i.e. the folded AttnBlock with C <= 512): the query projection q' = (Wk^T Wq) h + Wk^T bq -- the one GEMM the folded block still
+// launched -- runs as phase 0 on the workgroup's own 64 queries, exactly like proj_out runs as phase 3: the 64 rows of h in LDS as 32-channel planes, Mq streamed through a ring
+// of three 32 KB chunks, the result rounded to 16 bits (as the GEMM stored it) into the [64-channel step][query row] image phase 1 reads its query fragments from.  Phase 1's
+// stages then hold key rows only (32 KB instead of 40).  Same MFMA sequence per output and the same rounding as the stand-alone GEMM, hence the same bits: the whole AttnBlock
+// behind its GroupNorm is ONE launch.
 struct AttnFusedCfg {
     static constexpr int N = 256, QB = 64, NTHREADS = 512;
     static constexpr int ST1 = (N + QB) * 128;                 // 40 KB: K rows then Q rows of one 64-channel step
@@ -61,8 +72,9 @@ struct AttnFusedCfg {
     static_assert(3 * ST1 <= RED_OFF && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <bool PROJ, typename T_ = __bf16, bool VTOK = false>
+template <bool PROJ, typename T_ = __bf16, bool VTOK = false, bool QPROJ = false>
 __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs a, const ConvArgs pe) {
+    static_assert(!QPROJ || (PROJ && VTOK), "the in-kernel query projection belongs to the folded AttnBlock with proj_out fused");
     using C = AttnFusedCfg;
     using T = T_;
     constexpr int N = C::N, QB = C::QB;
@@ -103,10 +115,26 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         const int tok = isk ? row : qb * QB + (row - N);
         v1[j] = (unsigned)(((long long)b * N + tok) * (isk ? a.k_ld : a.q_ld) * 2 + u * 16);
     }
+    constexpr int ST1Q = N * 128;                                     // QPROJ: a phase-1 stage holds the 256 key rows only (32 KB); q' lives at Q_OFF
+    constexpr int Q_OFF = 3 * ST1Q;                                   // 96 KB: eight [64 query rows][128 B] planes = 64 KB
+    if constexpr (QPROJ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + (lane >> 3);          // key row
+            const int u = (lane & 7) ^ ((row >> 1) & 7);
+            v1[j] = (unsigned)(((long long)b * N + row) * a.k_ld * 2 + u * 16);
+        }
+    }
     auto issue1 = [&](int step, int buf) __attribute__((always_inline)) {
+        if constexpr (QPROJ) {
+            const unsigned base = lds0 + buf * ST1Q + wave * (4 * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma16(q_k, base + j * 1024, v1[j], step * 128);
+        } else {
         const unsigned base = lds0 + buf * C::ST1 + wave * (5 * 1024);
 #pragma unroll
         for (int j = 0; j < 5; ++j) dma16(wave * 5 + j < N / 8 ? q_k : q_q, base + j * 1024, v1[j], step * 128);          // (wave-uniform choice)
+        }
     };
     // ---- phase-2 DMA geometry: Cp / 16 pieces of 16 rows x 64 B per 32-key chunk (conv kernel's rotated 64-byte rows); Cp = channels per pass
     const int npass = Cc > C::MAX_CP ? 2 : 1;
@@ -154,24 +182,102 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
 #pragma unroll
         for (int j = 0; j < 2; ++j) s_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = Cc / 64;
+    if constexpr (QPROJ) {
+        // =========================== phase 0: q'^T = Mq . h_q^T (+ cq), 16-bit, into the query image of phase 1 ===========================
+        // LDS: h_q as Cc / 32 planes of [64 query rows][64 B] (the conv kernels' rotated rows) at 0 (<= 64 KB), Mq chunks (Cc rows x 32 channels = 32 KB) in a ring of
+        // three behind it; waves = 8 blocks of 64 output channels; a wave reads only the Mq rows it fetched itself when C = 512 (own_rows), as in phase 3
+        constexpr int HQ_BYTES = QB * 512 * 2, ST0 = 512 * 64;
+        static_assert(HQ_BYTES + 3 * ST0 <= 160 * 1024 && Q_OFF + QB * 512 * 2 <= 160 * 1024, "LDS");
+        const i32x4 q_mw = make_q(a.qw, a.qw_bytes);
+        const int np0 = Cc / 32;                                       // planes of h_q
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                  // 4 pieces of 16 rows per plane: piece = plane * 4 + row block
+            const int piece = wave * 8 + j;
+            const int pl = piece >> 2, row = (piece & 3) * 16 + (lane >> 2);
+            if (pl < np0) dma16(q_k, lds0 + piece * 1024, (unsigned)(((long long)b * N + qb * QB + row) * a.k_ld * 2 + un2 * 16), pl * 64);
+        }
+        unsigned v0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 16 + (lane >> 2);         // output channel
+            v0[j] = row < Cc ? (unsigned)(row * a.qw_ld * 2 + un2 * 16) : 0xFFFF0000u;
+        }
+        auto issue0 = [&](int chunk, int buf) __attribute__((always_inline)) {
+            const unsigned base = lds0 + HQ_BYTES + buf * ST0 + wave * (4 * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma16(q_mw, base + j * 1024, v0[j], chunk * 64);
+        };
+        issue0(0, 0);
+        issue0(1, 1);
+        f32x4 y_acc[4][4];                                             // [query block][channel block]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ku0 = lane >> 4;
+        const int wa_off = HQ_BYTES + lds_off(wave * 64 + (lane & 15), ku0);
+        const int hb_off = lds_off(lane & 15, ku0);
+        const bool own0 = Cc == 512;
+        int buf = 0;
+        for (int k = 0; k < np0; ++k) {
+            if (k + 1 < np0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (k == 0 || !own0) __builtin_amdgcn_s_barrier();         // k = 0: every wave's pieces of h_q are in
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < np0) issue0(k + 2, buf >= 1 ? buf - 1 : 2);
+            const char* wb = smem + buf * ST0;
+            const char* hb = smem + k * (QB * 64);
+            uint4 wf[4], hf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + wa_off + j * (16 * 64));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hf[i] = *(const uint4*)(hb + hb_off + i * (16 * 64));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16t<T>(y_acc[i][j], hf[i], wf[j]);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // every wave is done with h_q and the ring
+        __builtin_amdgcn_sched_barrier(0);
+        issue1(0, 0);                                                  // the first key stages travel while q' is written
+        if (nk > 1) issue1(1, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c0 = wave * 64 + j * 16 + (lane >> 4) * 4;       // four consecutive output channels
+            const float4 cb = (a.qbias != nullptr && c0 < Cc) ? *(const float4*)(a.qbias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int plane = c0 >> 6, unit = (c0 & 63) >> 3, half = (c0 >> 2) & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qn = i * 16 + (lane & 15);
+                // (the GEMM's epilogue: fma(acc, 1, bias), one rounding)
+                const uint2 qv = make_uint2(TI<T>::pack2(__builtin_fmaf(y_acc[i][j][0], 1.0f, cb.x), __builtin_fmaf(y_acc[i][j][1], 1.0f, cb.y)),
+                                            TI<T>::pack2(__builtin_fmaf(y_acc[i][j][2], 1.0f, cb.z), __builtin_fmaf(y_acc[i][j][3], 1.0f, cb.w)));
+                if (c0 < Cc) *(uint2*)(smem + Q_OFF + plane * (QB * 128) + qn * 128 + ((unit ^ ((qn >> 1) & 7)) << 4) + half * 8) = qv;
+            }
+        }
+    } else {
     issue1(0, 0);
     if (nk > 1) issue1(1, 1);
+    }
     {
         int buf = 0;
         for (int k = 0; k < nk; ++k) {
-            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            if (k + 1 < nk) { if constexpr (QPROJ) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < nk) issue1(k + 2, buf >= 1 ? buf - 1 : 2);
-            const char* base = smem + buf * C::ST1;
+            const char* base = smem + buf * (QPROJ ? ST1Q : C::ST1);
+            const char* qbase = QPROJ ? smem + Q_OFF + k * (QB * 128) - N * 128 : base;      // (b_off carries the N * 128 of the stage image)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 af[4], bf[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i] = *(const uint4*)(base + a_off[ks] + i * (16 * 128));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *(const uint4*)(base + b_off[ks] + j * (16 * 128));
+                for (int j = 0; j < 2; ++j) bf[j] = *(const uint4*)(qbase + b_off[ks] + j * (16 * 128));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll

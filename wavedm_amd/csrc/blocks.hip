@@ -95,7 +95,7 @@ void env_cfg_refresh() {
     auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e ? (e[0] == '0' ? 0 : 1) : dflt; };
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
-    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 2); c->attn_fold = num("WDM_ATTN_FOLD", 1);
+    c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 3); c->attn_fold = num("WDM_ATTN_FOLD", 1);
     c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
@@ -392,17 +392,26 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
         // Folded form (k_attn_fold; 16-bit modes): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((M h_i + cq).h_j) and proj_out(P.(Wv h + bv)) = Wvp (P.h) + bvp, so
         // the normalised input itself is K and V of the core: ONE projection GEMM (q' = M h + cq) instead of three, no V^T tensor, and proj_out runs on Wvp.
         Tens qf, o;
-        WDM_TRY(run_conv(c, w.qf, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qf, Y_NHWC, nullptr));      // [B][N][C]
+        const bool proj_in = C <= 512 && env_cfg().attn_fused >= 2 && x.H == 16 && x.W == 16;
+        // WDM_ATTN_FUSED=3: q' = Mq h + cq as phase 0 of the core (attn_fused_kernel.h: QPROJ) -- same MFMA sequence and rounding as the GEMM it replaces, hence the same bits
+        const bool q_in = proj_in && env_cfg().attn_fused >= 3 && w.qf.b != nullptr;
         AttnOperands in;
-        in.q = qf.p; in.q_ld = qf.xs; in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1;
-        if (C <= 512 && env_cfg().attn_fused >= 2 && x.H == 16 && x.W == 16) {
+        in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1;
+        if (q_in) {
+            in.qw = w.qf.w; in.qbias = w.qf.b; in.qw_ld = w.qf.cin; in.qw_bytes = (size_t)w.qf.rows_pad * w.qf.cin * es;
+        } else {
+            WDM_TRY(run_conv(c, w.qf, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qf, Y_NHWC, nullptr));      // [B][N][C]
+            in.q = qf.p; in.q_ld = qf.xs;
+        }
+        if (proj_in) {
             ConvArgs a_proj{};
             Tens odummy;
-            odummy.p = qf.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
+            odummy.p = hn.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
             WDM_TRY(run_conv(c, w.pf, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
                              next_fin));
             if (!c.dry) WDM_TRY(launch_attn_fused(in, nullptr, c.B, C, c.s, nullptr, &a_proj, c.dtype));
-            free_tens(c, qf); free_tens(c, hn);
+            if (!q_in) free_tens(c, qf);
+            free_tens(c, hn);
             return WDM_OK;
         }
         WDM_TRY(alloc_tens(c, C, x.H, x.W, &o));

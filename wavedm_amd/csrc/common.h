@@ -210,6 +210,9 @@ struct AttnOperands {
     const void* q = nullptr; const void* k = nullptr; const void* v = nullptr;
     int q_ld = 0, k_ld = 0, v_ld = 0;      // elements per token row (v_ld: token-major V only)
     int v_tok = 0;
+    // folded AttnBlock with proj_out fused (C <= 512): the query projection inside the kernel (attn_fused_kernel.h: QPROJ) -- q is then null and qw / qbias are the
+    // folded [C][qw_ld] 16-bit matrix Wk^T Wq and its fp32 bias Wk^T bq
+    const void* qw = nullptr; const float* qbias = nullptr; int qw_ld = 0; size_t qw_bytes = 0;
 };
 // vbias != nullptr: V was computed without the v bias, which is added to the output instead
 // proj != nullptr (C <= 512): proj_out fused in as a third phase; *proj = the 1x1 conv's arguments as run_conv builds them (weights, bias, residual, output,
@@ -233,7 +236,8 @@ struct EnvCfg {
                           // left group partials (maps up to 32 x 32, single input: gn_inline.h); 2: everything else finalised by the PRODUCER's last workgroups (gn_arrive.h: built
                           // in round 4, bit-identical to the launches, 3.6 % SLOWER end to end -- one workgroup per image reduces what 2 048 waves of gn_finalize do side by side)
     int attn_fold = 1;    // WDM_ATTN_FOLD=0: the AttnBlock keeps its k and v projections (16-bit modes; blocks.hip: run_attn); 1: folded into q and proj_out at load time
-    int attn_fused = 2;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well
+    int attn_fused = 3;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well;
+                          // 3 (default): the folded block's query projection too (C = 128 ... 512 on 16 x 16 maps): the AttnBlock behind its GroupNorm is one launch
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: the batched-GEMM form of the weight gradient everywhere, n images per group (0: direct kernel for 3x3 stride-1 layers, training)
 };
