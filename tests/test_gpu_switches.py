@@ -121,6 +121,7 @@ def test_query_projection_inside_the_attention_core_gives_the_same_bits(gu, dtyp
         assert any(n.startswith("attn_fused_n256tq") for n in k3) and not any(n.startswith("gemm_1x1") or n.startswith("conv_1x1") for n in k3), k3
         assert any(n.startswith("gemm_1x1") or n.startswith("conv_1x1") for n in k2) and not any("n256tq" in n for n in k2), k2
         assert torch.isfinite(y).all() and torch.equal(y, y2), C
+        assert torch.equal(y, _with({"WDM_ATTN_SM": "0"}, run)[0]), C          # slab-major or plain copies of the folded matrices: the same numbers
         assert rel_linf(y, gu.attn(sd, "at", x, "f32")) <= gu.TOL[dtype]
 
 
@@ -150,7 +151,7 @@ def test_attention_block_on_folded_operands(gu, dtype):
         print(f"attn {dtype} C={C}: folded {e1:.2e}  k / v projections {e0:.2e}")
         assert torch.isfinite(y).all() and e1 <= gu.TOL[dtype] and e0 <= gu.TOL[dtype]
         assert any(n.startswith("attn_fused_n256t") for n in k1) and not any(n.startswith("attn_fused_n256t") for n in k0), (k1, k0)      # ("n256tq": with the query projection inside)
-        assert len(k1) == len(k0) - 1, (k1, k0)                      # q' instead of q|k and V^T
+        assert len(k1) == len(k0) - (2 if C <= 512 else 1), (k1, k0)      # q' instead of q|k and V^T -- and q' inside the core where proj_out is (C <= 512)
         assert torch.equal(y, run()[0])
 
 

@@ -18,7 +18,7 @@ struct Scratch {
     }
 };
 
-int pack_conv_w(Scratch& sc, const float* w, const float* b, int cin, int cout, int k, int dtype, hipStream_t s, ConvW* out) {
+int pack_conv_w(Scratch& sc, const float* w, const float* b, int cin, int cout, int k, int dtype, hipStream_t s, ConvW* out, bool sm_1x1 = false) {
     char* dst;
     WDM_TRY(sc.get<char>(conv_packed_bytes(cin, cout, k, dtype), &dst));
     out->cin = cin; out->cout = cout; out->k = k; out->rows_pad = conv_rows_pad(cout);
@@ -28,6 +28,11 @@ int pack_conv_w(Scratch& sc, const float* w, const float* b, int cin, int cout, 
         char* sm;
         WDM_TRY(sc.get<char>(conv_packed_bytes(cin, cout, k, dtype), &sm));
         WDM_TRY(k_pack_conv_sm(w, cout, cin, sm, out->rows_pad, s, dtype));
+        out->w_sm = sm;
+    } else if (sm_1x1 && k == 1 && is_h16(dtype) && cin % 32 == 0) {      // the folded AttnBlock's matrices: [cin / 32][rows][32] for the fused core (unet.hip: refold)
+        char* sm;
+        WDM_TRY(sc.get<char>(conv_packed_bytes(cin, cout, k, dtype), &sm));
+        WDM_TRY(k_pack_conv_sm(w, cout, cin, sm, out->rows_pad, s, dtype, 1));
         out->w_sm = sm;
     }
     return WDM_OK;
@@ -149,8 +154,8 @@ int wdm_attn_forward(wdm_handle* h, const wdm_attn_params* p, const float* x, in
         WDM_TRY(sc.get<float>((size_t)C * C, &Wvp));
         WDM_TRY(sc.get<float>((size_t)C, &bvp));
         WDM_TRY(k_attn_fold(p->q_w, p->q_b, p->k_w, p->v_w, p->v_b, p->proj_w, p->proj_b, C, M, cq, Wvp, bvp, c.s));
-        WDM_TRY(pack_conv_w(sc, M, cq, C, C, 1, dtype, c.s, &w.qf));
-        WDM_TRY(pack_conv_w(sc, Wvp, bvp, C, C, 1, dtype, c.s, &w.pf));
+        WDM_TRY(pack_conv_w(sc, M, cq, C, C, 1, dtype, c.s, &w.qf, true));
+        WDM_TRY(pack_conv_w(sc, Wvp, bvp, C, C, 1, dtype, c.s, &w.pf, true));
     }
     Tens t0, out;
     WDM_TRY(to_nhwc(sc, c, x, C, H, W, &t0));

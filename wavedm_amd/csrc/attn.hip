@@ -31,7 +31,7 @@ static int launch_attn_fused_t(const AttnOperands& in, void* o, int B, int C, hi
     a.q_ld = in.q_ld; a.k_ld = in.k_ld; a.v_ld = in.v_ld;
     a.alpha = (float)std::pow((double)C, -0.5);
     // extents behind the three pointers (q and k may be column ranges of one tensor: the last row ends C elements behind its start)
-    a.qw = in.qw; a.qbias = in.qbias; a.qw_ld = in.qw_ld; a.qw_bytes = (unsigned)in.qw_bytes;
+    a.qw = in.qw; a.qbias = in.qbias; a.qw_ld = in.qw_ld; a.qw_bytes = (unsigned)in.qw_bytes; a.qw_slab = in.qw_slab;
     a.q_bytes = qproj ? 0u : (unsigned)(qb - (in.q_ld - C) * 2.0); a.k_bytes = (unsigned)(kb - (in.k_ld - C) * 2.0); a.v_bytes = (unsigned)(VTOK ? vb - (in.v_ld - C) * 2.0 : vb);
     static std::atomic<unsigned> devs{0};
     int dev = 0;

@@ -42,6 +42,7 @@ struct AttnFusedArgs {
     const float* qbias;  // [C]: cq = Wk^T bq
     int qw_ld;
     unsigned qw_bytes;
+    int qw_slab;         // 0: plain [C][qw_ld]; else slab-major [C / 32][rows][32], elements between slabs
 };
 
 // VTOK = true: V arrives token-major -- the layout every conv / GEMM epilogue writes -- and phase 2 builds its channel-row fragments with ds_read_b64_tr_b16
@@ -200,12 +201,14 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (wave * 4 + j) * 16 + (lane >> 2);         // output channel
-            v0[j] = row < Cc ? (unsigned)(row * a.qw_ld * 2 + un2 * 16) : 0xFFFF0000u;
+            // slab-major copy: a 1 KB piece (16 rows x 64 B) is one contiguous run of whole cache lines; the plain matrix gives 16 half lines a kilobyte apart
+            v0[j] = row < Cc ? (unsigned)((a.qw_slab ? row * 32 : row * a.qw_ld) * 2 + un2 * 16) : 0xFFFF0000u;
         }
+        const int qstep = a.qw_slab ? a.qw_slab * 2 : 64;             // bytes between 32-channel chunks
         auto issue0 = [&](int chunk, int buf) __attribute__((always_inline)) {
             const unsigned base = lds0 + HQ_BYTES + buf * ST0 + wave * (4 * 1024);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma16(q_mw, base + j * 1024, v0[j], chunk * 64);
+            for (int j = 0; j < 4; ++j) dma16(q_mw, base + j * 1024, v0[j], chunk * qstep);
         };
         issue0(0, 0);
         issue0(1, 1);
@@ -441,18 +444,20 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
         constexpr int O_BYTES = QB * 512 * 2;                              // 64 KB: the image of 512 channels (C <= 512: host check)
         constexpr int ST3 = 512 * 64;                                      // 32 KB: W_p rows (output channels) x 32 input channels
         static_assert(O_BYTES + 3 * ST3 <= 160 * 1024, "LDS");
-        const i32x4 q_w = make_q(pe.w, pe.w_bytes);
+        const bool sm3 = pe.w_sm != nullptr;                              // the slab-major copy [C / 32][w_rows][32] of Wp Wv (blocks.hip: run_attn)
+        const i32x4 q_w = make_q(sm3 ? pe.w_sm : pe.w, pe.w_bytes);
         unsigned v3[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int piece = wave * 4 + j;
             const int row = piece * 16 + (lane >> 2);                      // output channel
-            v3[j] = row < pe.w_rows && row < Cc ? (unsigned)(row * pe.w_row_stride * 2 + un2 * 16) : 0xFFFF0000u;
+            v3[j] = row < pe.w_rows && row < Cc ? (unsigned)((sm3 ? row * 32 : row * pe.w_row_stride) * 2 + un2 * 16) : 0xFFFF0000u;
         }
+        const int wstep = sm3 ? pe.w_rows * 64 : 64;                      // bytes between 32-channel chunks
         auto issue3 = [&](int chunk, int buf) __attribute__((always_inline)) {
             const unsigned base = lds0 + O_BYTES + buf * ST3 + wave * (4 * 1024);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma16(q_w, base + j * 1024, v3[j], chunk * 64);
+            for (int j = 0; j < 4; ++j) dma16(q_w, base + j * 1024, v3[j], chunk * wstep);
         };
         issue3(0, 0);
         issue3(1, 1);

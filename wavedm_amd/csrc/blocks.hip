@@ -96,7 +96,7 @@ void env_cfg_refresh() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     c->conv_dma = flag("WDM_CONV_DMA", 1); c->gemm = flag("WDM_GEMM", 1); c->bn256 = num("WDM_BN256", 1);
     c->gn_tile = num("WDM_GN_TILE", 2); c->gn_inline = num("WDM_GN_INLINE", 1); c->attn_fused = num("WDM_ATTN_FUSED", 3); c->attn_fold = num("WDM_ATTN_FOLD", 1);
-    c->up4 = flag("WDM_UP4", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
+    c->up4 = flag("WDM_UP4", 1); c->attn_sm = flag("WDM_ATTN_SM", 1); c->wgrad_bg = num("WDM_WGRAD_BG", 0);
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env.store(c, std::memory_order_release);
 }
@@ -398,7 +398,9 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
         AttnOperands in;
         in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1;
         if (q_in) {
-            in.qw = w.qf.w; in.qbias = w.qf.b; in.qw_ld = w.qf.cin; in.qw_bytes = (size_t)w.qf.rows_pad * w.qf.cin * es;
+            const bool sm = env_cfg().attn_sm && w.qf.w_sm != nullptr;
+            in.qw = sm ? w.qf.w_sm : w.qf.w; in.qw_slab = sm ? w.qf.rows_pad * 32 : 0;
+            in.qbias = w.qf.b; in.qw_ld = w.qf.cin; in.qw_bytes = (size_t)w.qf.rows_pad * w.qf.cin * es;
         } else {
             WDM_TRY(run_conv(c, w.qf, MODE_P1, hn, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, &qf, Y_NHWC, nullptr));      // [B][N][C]
             in.q = qf.p; in.q_ld = qf.xs;
@@ -409,6 +411,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
             odummy.p = hn.p; odummy.C = C; odummy.H = x.H; odummy.W = x.W; odummy.xs = C;           // stands for O in run_conv's shape checks only
             WDM_TRY(run_conv(c, w.pf, MODE_P1, odummy, nullptr, nullptr, nullptr, nullptr, 0, 0, &x, out, Y_NHWC, nullptr, true, nullptr, nullptr, nullptr, nullptr, &a_proj, nullptr, 0,
                              next_fin));
+            if (env_cfg().attn_sm && w.pf.w_sm) a_proj.w_sm = w.pf.w_sm;      // phase 3 streams the slab-major copy of Wp Wv
             if (!c.dry) WDM_TRY(launch_attn_fused(in, nullptr, c.B, C, c.s, nullptr, &a_proj, c.dtype));
             if (!q_in) free_tens(c, qf);
             free_tens(c, hn);

@@ -101,7 +101,7 @@ struct Ctx {
 struct ConvW {
     const void* w = nullptr;   // [taps][rows_pad][cin] model dtype
     const void* w_up4 = nullptr;   // Upsample convs, bf16: the 16 pre-summed sub-pixel taps (k_pack_up4), or nullptr
-    const void* w_sm = nullptr;    // bf16 3x3 convs: slab-major copy [cin / 32][tap][rows_pad][32] (k_pack_conv_sm), or nullptr
+    const void* w_sm = nullptr;    // bf16 3x3 convs: slab-major copy [cin / 32][tap][rows_pad][32] (k_pack_conv_sm), or nullptr; the folded AttnBlock's qf / pf: [cin / 32][rows_pad][32]
     const float* b = nullptr;  // [cout]
     int cin = 0, cout = 0, k = 1, rows_pad = 0;
 };
@@ -183,7 +183,7 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
 // here it is one contiguous run of 8 whole lines (15 cycles)
 // (f32x3 mode: the same slot holds the pre-split copy of conv_dmax3_kernel.h, plain [tap][row][cin] order, 16-channel groups as [hi | hi | lo | lo])
 inline bool conv_sm_eligible(int dtype, int k, int cin) { return (is_h16(dtype) && k == 3 && cin % 32 == 0) || (dtype == WDM_F32X3 && k == 3 && cin % 16 == 0); }
-int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
+int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16, int k = 3);      // k = 1: [cin / 32][rows][32] of a 1x1 matrix
 int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype = WDM_BF16);
 bool conv_up4_eligible(int dtype, int H, int W, int cin, int cout);      // sub-pixel Upsample kernel applies to this low-resolution map
 int k_pad_channels(const void* x, int C, int Cp, void* y, long long rows, int dtype, hipStream_t s);
@@ -213,6 +213,7 @@ struct AttnOperands {
     // folded AttnBlock with proj_out fused (C <= 512): the query projection inside the kernel (attn_fused_kernel.h: QPROJ) -- q is then null and qw / qbias are the
     // folded [C][qw_ld] 16-bit matrix Wk^T Wq and its fp32 bias Wk^T bq
     const void* qw = nullptr; const float* qbias = nullptr; int qw_ld = 0; size_t qw_bytes = 0;
+    int qw_slab = 0;     // 0: qw is the plain [C][qw_ld] matrix; else it is the slab-major copy [C / 32][rows][32] and this the elements between slabs (rows x 32)
 };
 // vbias != nullptr: V was computed without the v bias, which is added to the output instead
 // proj != nullptr (C <= 512): proj_out fused in as a third phase; *proj = the 1x1 conv's arguments as run_conv builds them (weights, bias, residual, output,
@@ -238,6 +239,7 @@ struct EnvCfg {
     int attn_fold = 1;    // WDM_ATTN_FOLD=0: the AttnBlock keeps its k and v projections (16-bit modes; blocks.hip: run_attn); 1: folded into q and proj_out at load time
     int attn_fused = 3;   // WDM_ATTN_FUSED=0: attention core as three launches (Q.K^T, softmax, P.V); 1: fused core, proj_out as its own GEMM; 2: proj_out fused in as well;
                           // 3 (default): the folded block's query projection too (C = 128 ... 512 on 16 x 16 maps): the AttnBlock behind its GroupNorm is one launch
+    int attn_sm = 1;      // WDM_ATTN_SM=0: the fused attention core streams Wk^T Wq / Wp Wv from the plain [row][cin] matrices (64-byte half lines per row) instead of their slab-major copies
     int up4 = 1;          // WDM_UP4=0: 9-tap Upsample conv everywhere (no sub-pixel form)
     int wgrad_bg = 0;     // WDM_WGRAD_BG=<n>: the batched-GEMM form of the weight gradient everywhere, n images per group (0: direct kernel for 3x3 stride-1 layers, training)
 };

@@ -645,14 +645,14 @@ int k_pack_conv(const float* w_oihw, int cout, int cin, int k, void* dst, int ro
     return WDM_OK;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total) {
-    const long long total = (long long)9 * rows_total * cin;
+__global__ __launch_bounds__(256) void pack_conv_sm_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total, int taps) {
+    const long long total = (long long)taps * rows_total * cin;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id & 31);
         const int o = (int)((id >> 5) % rows_total);
-        const int tap = (int)((id / ((long long)32 * rows_total)) % 9);
-        const int slab = (int)(id / ((long long)32 * rows_total * 9));
-        const float v = o < cout ? w[((long long)o * cin + slab * 32 + c) * 9 + tap] : 0.f;
+        const int tap = (int)((id / ((long long)32 * rows_total)) % taps);
+        const int slab = (int)(id / ((long long)32 * rows_total * taps));
+        const float v = o < cout ? w[((long long)o * cin + slab * 32 + c) * taps + tap] : 0.f;
         TI<T>::st(dst, id, v);
     }
 }
@@ -679,8 +679,9 @@ __global__ __launch_bounds__(256) void pack_conv_x3_kernel(const float* __restri
         ph[0] = hi[0]; ph[1] = hi[1]; ph[8] = lo[0]; ph[9] = lo[1];
     }
 }
-int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype) {
+int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_total, hipStream_t s, int dtype, int k) {
     if (dtype == WDM_F32X3) {
+        if (k != 3) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: the f32x3 pre-split copy is for 3x3 convs");
         if (cin % 16) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 16", cin);
         const long long total = (long long)9 * rows_total * (cin / 4);
         hipLaunchKernelGGL(pack_conv_x3_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 65535)), dim3(256), 0, s, w_oihw, cout, cin, (unsigned*)dst, rows_total);
@@ -689,9 +690,9 @@ int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_t
     }
 
     if (cin % 32) WDM_FAIL(WDM_EINVAL, "k_pack_conv_sm: cin %d is not a multiple of 32", cin);
-    const long long total = (long long)9 * rows_total * cin;
+    const long long total = (long long)k * k * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_conv_sm_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (H16*)dst, rows_total));
+    WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_conv_sm_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (H16*)dst, rows_total, k * k));
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }

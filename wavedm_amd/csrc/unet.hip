@@ -141,7 +141,8 @@ struct wdm_unet {
             // the folded operands the fused core runs on (blocks.hip: run_attn), rebuilt by wdm_unet_load_param whenever one of the seven tensors behind them arrives
             FoldD f{};
             f.c = c;
-            auto plain = [&](ConvD& d) { d = ConvD{}; d.cin = c; d.cout = c; d.k = 1; d.rows_pad = conv_rows_pad(c); d.w_off = take(conv_packed_bytes(c, c, 1, cfg.dtype)); d.b_off = take((size_t)c * 4); };
+            auto plain = [&](ConvD& d) { d = ConvD{}; d.cin = c; d.cout = c; d.k = 1; d.rows_pad = conv_rows_pad(c); d.w_off = take(conv_packed_bytes(c, c, 1, cfg.dtype)); d.b_off = take((size_t)c * 4);
+                                        if (c % 32 == 0) d.sm_off = take(conv_packed_bytes(c, c, 1, cfg.dtype)); };      // + the slab-major copy the fused core streams (attn_fused_kernel.h)
             plain(a.qf); plain(a.pf);
             f.stage_off = take((size_t)4 * c * c * 4);
             f.qk = a.qk; f.v = a.v; f.proj = a.proj; f.qf = a.qf; f.pf = a.pf;
@@ -284,7 +285,9 @@ int wdm_unet::refold(const ParamSlot& p, const float* dev_src, hipStream_t s) {
                             tmp, (float*)(packed + dst.b_off), s));
     }
     if (cfg.dtype == WDM_F16) WDM_TRY(check_f16_range(tmp, (int64_t)cc, qk_side ? "Wk^T Wq of an AttnBlock" : "Wp Wv of an AttnBlock", s));
-    return k_pack_conv(tmp, f.c, f.c, 1, packed + dst.w_off, dst.rows_pad, 0, 1, cfg.dtype, s);
+    WDM_TRY(k_pack_conv(tmp, f.c, f.c, 1, packed + dst.w_off, dst.rows_pad, 0, 1, cfg.dtype, s));
+    if (dst.sm_off) WDM_TRY(k_pack_conv_sm(tmp, f.c, f.c, packed + dst.sm_off, dst.rows_pad, s, cfg.dtype, 1));
+    return WDM_OK;
 }
 
 int wdm_unet::temb_table(Ctx& c, const float* t, int n_t, float* temb_all) {
