@@ -145,7 +145,7 @@ int run_conv(Ctx& c, const ConvW& w, int mode, const Tens& x0, const Tens* x1, c
     a.Cin = Cin; a.Cout = w.cout;
     a.w = w.w; a.w_tap_stride = (long long)w.rows_pad * w.cin; a.w_img_stride = 0; a.w_row_stride = w.cin; a.w_rows = w.rows_pad;
     a.w_bytes = (unsigned)((size_t)w.k * w.k * w.rows_pad * w.cin * dsize(c.dtype));
-    a.w_sm = (mode == MODE_S1 && w.k == 3) ? w.w_sm : nullptr;
+    a.w_sm = ((mode == MODE_S1 || (mode == MODE_S2 && is_h16(c.dtype))) && w.k == 3) ? w.w_sm : nullptr;
     a.bias = w.b; a.alpha = 1.0f;
     a.pro = (scale || gn_inl) ? 1 : 0; a.scale = scale; a.shift = shift;
     if (gn_inl) {

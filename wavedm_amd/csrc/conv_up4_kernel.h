@@ -73,7 +73,9 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
         return i32x4{(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
     };
     const i32x4 q_x0 = make_q(a.x0, a.x0_bytes);
-    const i32x4 q_w = make_q((const T*)a.w + (long long)phase * 4 * a.w_tap_stride, (unsigned)(4 * a.w_tap_stride * 2));
+    // weights: slab-major [slab][phase * 4 + dy' * 2 + dx'][row][32] (k_pack_up4): the descriptor starts at this phase's taps of slab 0 and runs to the end of the tensor
+    const i32x4 q_w = make_q((const T*)a.w + (long long)phase * 4 * a.w_tap_stride, a.w_bytes - (unsigned)(phase * 4 * a.w_tap_stride * 2));
+    const int wslab = a.w_slab_stride ? a.w_slab_stride : C::BK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto dma16 = [&](const i32x4& rsrc, unsigned lds_addr, unsigned voff, int soff) __attribute__((always_inline)) {
         unsigned keep;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv_up4_kernel(const ConvArgs a) {
     // slabs past the end are clamped: the extra pieces land in buffers nobody reads again and keep the DMA counts (the vmcnt constants) uniform
     auto issue_b = [&](int s, int dxl, int ring) __attribute__((always_inline)) {
         const int sc_ = s < nslab ? s : nslab - 1;
-        const int soff = (int)(((long long)dxl * a.w_tap_stride + sc_ * C::BK) * 2);
+        const int soff = (int)(((long long)dxl * a.w_tap_stride + (long long)sc_ * wslab) * 2);
         const unsigned base = lds0 + C::B_OFF + ring * C::B_SUB;
 #pragma unroll
         for (int i = 0; i < BCP; ++i) dma16(q_w, base + (wave * BCP + i) * 1024, b_v[i], soff);

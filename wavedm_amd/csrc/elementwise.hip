@@ -696,7 +696,8 @@ int k_pack_conv_sm(const float* w_oihw, int cout, int cin, void* dst, int rows_t
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }
-// Upsample in sub-pixel form (conv_up4_kernel.h): OIHW f32 3x3 -> [phase = 2 py + px][dy'][dx'][rows_total][cin] bf16, the taps of the
+// Upsample in sub-pixel form (conv_up4_kernel.h): OIHW f32 3x3 -> SLAB-MAJOR [cin / 32][phase = 2 py + px][dy'][dx'][rows_total][32] 16-bit (round 5: every 1 KB
+// LDS-DMA piece of the kernel -- 16 rows x 64 B -- is then one run of whole cache lines; as [tap][row][cin] it was 16 half lines a row apart), the taps of the
 // upsampled grid that fall on the same low-resolution pixel summed in fp32:  py = 0: {w0}, {w1 + w2};  py = 1: {w0 + w1}, {w2}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__ w, int cout, int cin, T* __restrict__ dst, int rows_total) {
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void pack_up4_kernel(const float* __restrict__
             for (int ty = y0; ty <= y1; ++ty)
                 for (int tx = x0; tx <= x1; ++tx) v += p[ty * 3 + tx];
         }
-        TI<T>::st(dst, id, v);
+        TI<T>::st(dst, (((long long)(ci >> 5) * 16 + t) * rows_total + o) * 32 + (ci & 31), v);
     }
 }
 // f32x3 mode (conv_up4x3_kernel.h): the same 16 pre-summed taps (fp32 sums), every 16-channel group split and laid out as [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
@@ -757,6 +758,7 @@ int k_pack_up4(const float* w_oihw, int cout, int cin, void* dst, int rows_total
         WDM_HIP(hipGetLastError());
         return WDM_OK;
     }
+    if (cin % 32) WDM_FAIL(WDM_EINVAL, "k_pack_up4: cin %d is not a multiple of 32", cin);
     const long long total = (long long)16 * rows_total * cin;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
     WDM_H16_SWITCH(dtype, hipLaunchKernelGGL(pack_up4_kernel<H16>, dim3(g), dim3(256), 0, s, w_oihw, cout, cin, (H16*)dst, rows_total));

@@ -79,8 +79,8 @@ struct wdm_unet {
         params.push_back(p);
     }
     // cin_pad > cin: the kernels' K dimension is padded with zero columns (conv_in of a model whose input width is not a multiple of 32)
-    // s1: a stride-1 conv -- the only 3x3 kind the LDS-DMA kernels take, hence the only one that gets the slab-major weight copy (Downsample / Upsample
-    // convs never read theirs: less to pack after every trainer sync, a smaller weight broadcast)
+    // s1: the conv gets the slab-major weight copy: stride-1 convs, and since round 5 the Downsample convs of the 16-bit modes (conv_s2_kernel.h); Upsample convs
+    // never read theirs (their sub-pixel taps are slab-major themselves: k_pack_up4): less to pack after every trainer sync, a smaller weight broadcast
     ConvD add_conv(const std::string& name, int cin, int cout, int k, int cin_pad = 0, bool s1 = true) {
         ConvD d{};
         if (cin_pad <= 0) cin_pad = cin;
@@ -208,7 +208,7 @@ int wdm_unet::build() {
         if (is_attn(res))
             for (int b = 0; b < nrb; ++b) down_attn[l].push_back(add_attn("down." + std::to_string(l) + ".attn." + std::to_string(b), block_out));
         if (l != nres - 1) {
-            down_ds[l] = add_conv("down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3, 0, false);
+            down_ds[l] = add_conv("down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3, 0, is_h16(cfg.dtype));      // (16-bit: conv_s2_kernel.h streams the slab-major copy)
             res /= 2;
         }
     }
