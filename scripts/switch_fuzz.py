@@ -13,7 +13,7 @@ from wavedm_amd import procedural as P, _lib        # noqa: E402
 
 torch.set_grad_enabled(False)
 SW = {"WDM_GN_TILE": "012", "WDM_GN_INLINE": "012", "WDM_BN256": "012", "WDM_CONV_DMA": "01", "WDM_GEMM": "01",
-      "WDM_UP4": "01", "WDM_ATTN_FUSED": "012", "WDM_ATTN_FOLD": "01"}        # every switch the library has (csrc/common.h: EnvCfg) but the trainer's WDM_WGRAD_BG: 2592 combinations
+      "WDM_UP4": "01", "WDM_ATTN_FUSED": "0123", "WDM_ATTN_FOLD": "01", "WDM_ATTN_SM": "01"}        # every switch the library has (csrc/common.h: EnvCfg) but the trainer's WDM_WGRAD_BG: 6912 combinations
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = random.Random(7)
 R = int(os.environ.get("R", "64"))

@@ -1,4 +1,4 @@
-"""Alternative code paths behind the (nine) environment switches must agree with the default ones: bit for bit where the arithmetic is the same (tilings, proj_out fused into the attention core, in-tile GroupNorm), within the bf16 bound where it is reordered (register-staged instead of LDS-DMA
+"""Alternative code paths behind the (ten) environment switches must agree with the default ones: bit for bit where the arithmetic is the same (tilings, proj_out fused into the attention core, in-tile GroupNorm), within the bf16 bound where it is reordered (register-staged instead of LDS-DMA
 kernels, GroupNorm finalised in the consumer's prologue)."""
 import os
 
