@@ -126,6 +126,55 @@ def test_query_projection_inside_the_attention_core_gives_the_same_bits(gu, dtyp
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_8x8_attention_block_on_the_block_diagonal_fused_core(gu, dtype):
+    """The AttnBlock of the 8 x 8 maps (64 tokens, C = 768 in the model): four images share one 256-row "image" of the fused core, a query block sees its own image's keys only
+    (the other three key blocks' scores are -inf before the softmax: attn_fused_kernel.h, bdiag), on the folded operands -- q' GEMM, core, proj_out GEMM instead of seven launches.
+    Any batch size: a ragged last group is skipped per query block, and an image's bits do not depend on the batch or on its place in a group."""
+    from wavedm_amd import _lib
+    for C in (768, 256):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("at8", shapes)
+        x = gu.seeded((6, C, 8, 8), 29)
+
+        def run(xx=x):
+            _lib.prof_enable(True)
+            out = gu.attn(sd, "at8", xx, dtype)
+            names = [e["kernel"].split("|")[0] for e in _lib.prof_report() for _ in range(int(e["launches"]))]
+            _lib.prof_enable(False)
+            return out, names
+        y, k1 = run()
+        y0, k0 = _with({"WDM_ATTN_FOLD": "0"}, run)
+        ref = gu.attn(sd, "at8", x, "f32")
+        assert any(n.startswith("attn_fused_n64x4t") for n in k1) and not any(n.startswith("attn_fused") for n in k0), (k1, k0)
+        assert len(k1) < len(k0), (k1, k0)
+        assert torch.isfinite(y).all() and rel_linf(y, ref) <= gu.TOL[dtype] and rel_linf(y0, ref) <= gu.TOL[dtype]
+        assert torch.equal(y, run()[0])                                       # deterministic
+        for sl in (slice(0, 1), slice(4, 6), slice(5, 6), slice(1, 4)):       # alone, as the ragged group, at another place of a group
+            assert torch.equal(y[sl], run(x[sl].contiguous())[0]), (C, sl)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fused_attention_core_is_bit_reproducible_at_every_width(gu, dtype):
+    """Regression (round 5): the token-major-V core's transposing LDS reads sat behind an `if (fragment exists) read; else zero` -- a control-flow merge between an
+    asynchronous read and its wait, where the compiler may copy a register the read has not filled yet.  C = 1024 in f16 (the only width using the fourth fragment without
+    proj_out) went non-deterministic, ~1e-2 off, when an unrelated line changed the schedule.  The reads are branch-free now; every width must repeat bit for bit."""
+    for C, B in ((1024, 3), (768, 2), (512, 5), (384, 3), (128, 2)):
+        shapes = {"norm.weight": (C,), "norm.bias": (C,)}
+        for k in ("q", "k", "v", "proj_out"):
+            shapes[k + ".weight"] = (C, C, 1, 1)
+            shapes[k + ".bias"] = (C,)
+        sd = gu.blk_sd("atr", shapes)
+        x = gu.seeded((B, C, 16, 16), 31)
+        y = gu.attn(sd, "atr", x, dtype)
+        for _ in range(4):
+            assert torch.equal(y, gu.attn(sd, "atr", x, dtype)), C
+        assert rel_linf(y, gu.attn(sd, "atr", x, "f32")) <= gu.TOL[dtype], C
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_attention_block_on_folded_operands(gu, dtype):
     """16-bit modes (blocks.hip: run_attn): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((Wk^T Wq h_i + Wk^T bq).h_j) and proj_out(P.(Wv h + bv)) = (Wp Wv)(P.h) + Wp bv + bp, so
     the block runs ONE projection GEMM and the fused core with the normalised input as K and as (token-major, transposing-read) V.  WDM_ATTN_FOLD=0 keeps the k / v

@@ -24,10 +24,13 @@ static int launch_attn_fused_t(const AttnOperands& in, void* o, int B, int C, hi
     if (proj && (C > 512 || proj->Cout != C || proj->Cin != C || proj->Hout != 16 || proj->Wout != 16 || proj->B != B || !proj->w || proj->w_bytes == 0 || proj->y_mode != Y_NHWC ||
                  proj->temb || proj->m_valid || proj->up4 || (proj->stats && proj->stats_nslab != 4)))
         WDM_FAIL(WDM_EINVAL, "attn(fused): proj_out epilogue arguments do not describe a C = %d 1x1 conv on 16 x 16 maps", C);
-    const double qb = (double)B * Cf::N * in.q_ld * 2.0, kb = (double)B * Cf::N * in.k_ld * 2.0, vb = VTOK ? (double)B * Cf::N * in.v_ld * 2.0 : (double)B * C * Cf::N * 2.0;
+    if (in.bdiag && (!VTOK || proj || qproj)) WDM_FAIL(WDM_EINVAL, "attn(fused): the block-diagonal form (64 tokens per image) takes token-major V and writes O");
+    const int NT = in.bdiag ? 64 : Cf::N;                 // tokens per real image
+    const int G = in.bdiag ? (B + 3) / 4 : B;             // "images" of the kernel
+    const double qb = (double)B * NT * in.q_ld * 2.0, kb = (double)B * NT * in.k_ld * 2.0, vb = VTOK ? (double)B * NT * in.v_ld * 2.0 : (double)B * C * Cf::N * 2.0;
     if (qb >= 4294901760.0 || kb >= 4294901760.0 || vb >= 4294901760.0) WDM_FAIL(WDM_EINVAL, "attn(fused): an operand exceeds the 4 GB buffer-offset range");
     AttnFusedArgs a{};
-    a.q = in.q; a.k = in.k; a.v = in.v; a.o = o; a.vbias = vbias; a.B = B; a.C = C;
+    a.q = in.q; a.k = in.k; a.v = in.v; a.o = o; a.vbias = vbias; a.B = G; a.C = C; a.bdiag = in.bdiag; a.nimg = B;
     a.q_ld = in.q_ld; a.k_ld = in.k_ld; a.v_ld = in.v_ld;
     a.alpha = (float)std::pow((double)C, -0.5);
     // extents behind the three pointers (q and k may be column ranges of one tensor: the last row ends C elements behind its start)
@@ -45,16 +48,17 @@ static int launch_attn_fused_t(const AttnOperands& in, void* o, int B, int C, hi
     const bool prof = prof_enabled();
     if (prof) {
         char name[96];
-        snprintf(name, sizeof(name), "attn_fused_n256%s%s_%s|16x16 C=%d%s%s", VTOK ? "t" : "", qproj ? "q" : "", std::is_same<T, f16_t>::value ? "f16" : "bf16", C, qproj ? " qproj+" : "", proj ? " +proj" : "");
-        prof_begin(s, name, 4.0 * B * Cf::N * (double)Cf::N * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0) + (qproj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
-                   (double)B * Cf::N * C * 2.0 * (qproj ? 3.0 : proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0) + (qproj ? (double)C * C * 2.0 : 0.0));
+        snprintf(name, sizeof(name), "attn_fused_n%s%s%s_%s|%s C=%d%s%s", in.bdiag ? "64x4" : "256", VTOK ? "t" : "", qproj ? "q" : "", std::is_same<T, f16_t>::value ? "f16" : "bf16",
+                 in.bdiag ? "8x8" : "16x16", C, qproj ? " qproj+" : "", proj ? " +proj" : "");
+        prof_begin(s, name, 4.0 * B * NT * (double)NT * C + (proj ? 2.0 * B * Cf::N * (double)C * C : 0.0) + (qproj ? 2.0 * B * Cf::N * (double)C * C : 0.0),
+                   (double)B * NT * C * 2.0 * (qproj ? 3.0 : proj ? 5.0 : 4.0) + (proj ? (double)C * C * 2.0 : 0.0) + (qproj ? (double)C * C * 2.0 : 0.0));
     }
     ConvArgs pe{};
     if (proj) pe = *proj;
     pe.fin_total = AttnFusedCfg::N / AttnFusedCfg::QB;          // gn_arrive.h: the image's query blocks
-    if (qproj) { if constexpr (VTOK) hipLaunchKernelGGL((attn_fused_kernel<true, T, true, true>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe); }
-    else if (proj) hipLaunchKernelGGL((attn_fused_kernel<true, T, VTOK>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
-    else hipLaunchKernelGGL((attn_fused_kernel<false, T, VTOK>), dim3(((B + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
+    if (qproj) { if constexpr (VTOK) hipLaunchKernelGGL((attn_fused_kernel<true, T, true, true>), dim3(((G + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe); }
+    else if (proj) hipLaunchKernelGGL((attn_fused_kernel<true, T, VTOK>), dim3(((G + 7) / 8) * 32), dim3(Cf::NTHREADS), 160 * 1024, s, a, pe);
+    else hipLaunchKernelGGL((attn_fused_kernel<false, T, VTOK>), dim3(((G + 7) / 8) * 32), dim3(Cf::NTHREADS), Cf::LDS_BYTES, s, a, pe);      // 8 images x 4 query blocks per group of 32
     if (prof) prof_end(s);
     WDM_HIP(hipGetLastError());
     return WDM_OK;

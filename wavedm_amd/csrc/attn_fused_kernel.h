@@ -43,6 +43,10 @@ struct AttnFusedArgs {
     int qw_ld;
     unsigned qw_bytes;
     int qw_slab;         // 0: plain [C][qw_ld]; else slab-major [C / 32][rows][32], elements between slabs
+    // block-diagonal form (round 5; the 8 x 8 maps' AttnBlock, N = 64 tokens): an "image" of the kernel is a group of FOUR real images (4 x 64 = 256 token rows, contiguous in
+    // [B][64][C] tensors), query block qb is real image 4 b + qb and attends to key block qb only -- the other three key blocks' scores are set to -inf before the softmax
+    // (their P is exactly 0, so O and everything behind it are the real image's attention); B = groups, nimg = real images (a last group may be ragged)
+    int bdiag, nimg;
 };
 
 // VTOK = true: V arrives token-major -- the layout every conv / GEMM epilogue writes -- and phase 2 builds its channel-row fragments with ds_read_b64_tr_b16
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int qb = seq & 3, b = (seq >> 2) * 8 + xcd;
     if (b >= a.B) return;
+    if (a.bdiag && b * 4 + qb >= a.nimg) return;                      // (ragged last group: this query block is no image)
     const int Cc = a.C;
 
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s_acc[i][j][r] *= sl2; m = fmaxf(m, s_acc[i][j][r]); }
+            for (int r = 0; r < 4; ++r) { s_acc[i][j][r] = (a.bdiag && wm != qb) ? -INFINITY : s_acc[i][j][r] * sl2; m = fmaxf(m, s_acc[i][j][r]); }      // (wm = this wave's key block)
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         if (lane < 16) red[wm * QB + wn * 32 + j * 16 + lane] = m;
@@ -393,12 +398,15 @@ __global__ __launch_bounds__(512, 2) void attn_fused_kernel(const AttnFusedArgs 
             if constexpr (VTOK) {
                 unsigned long long lo[4], hi[4];
                 const unsigned sb = buf * C::ST2;
+                // NO control flow between a transposing read and the wait behind it: the read fills its register asynchronously, and at a merge (`if (i < nfi) read; else
+                // zero`) the compiler may copy a register that has not been filled yet -- measured in round 5: C = 1024 in f16 turned non-deterministic (1e-2 off) when an
+                // unrelated line of the softmax changed the schedule.  Fragments i >= nfi re-read fragment 0 and are never multiplied.
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nfi) {
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i]) : "v"(va_tr[i] + sb) : "memory");
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i]) : "v"(va_tr[i] + sb + 4 * rowb) : "memory");
-                    } else { lo[i] = 0; hi[i] = 0; }
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned ad = (i < nfi ? va_tr[i] : va_tr[0]) + sb;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i]) : "v"(ad) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i]) : "v"(ad + 4 * rowb) : "memory");
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = *(const uint4*)(smem + pb_off[j] + pslot);
                 // the transposing reads are invisible to the compiler's wait-count bookkeeping: everything has landed behind this wait

@@ -388,7 +388,10 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
     WDM_TRY(materialize_gn(c, w.n, x, nullptr, 0, &hn));
 
     const bool fused = attn_fused_eligible(c.dtype, N, C);
-    if (fused && env_cfg().attn_fold && w.qf.w && w.pf.w && w.qf.cin == C && w.qf.cout == C && w.pf.cin == C && w.pf.cout == C) {
+    // the 8 x 8 maps' block (64 tokens): the fused core in its block-diagonal form -- four images per 256-row "image" of the kernel, scores outside an image's own block masked
+    // (attn_fused_kernel.h: bdiag) -- on the folded operands; any batch size (a ragged last group is skipped per query block), so an image's bits do not depend on the batch
+    const bool bdiag = N == 64 && attn_fused_eligible(c.dtype, 256, C) && x.H == 8 && x.W == 8;
+    if ((fused || bdiag) && env_cfg().attn_fold && w.qf.w && w.pf.w && w.qf.cin == C && w.qf.cout == C && w.pf.cin == C && w.pf.cout == C) {
         // Folded form (k_attn_fold; 16-bit modes): softmax_j((Wq h_i + bq).(Wk h_j + bk)) = softmax_j((M h_i + cq).h_j) and proj_out(P.(Wv h + bv)) = Wvp (P.h) + bvp, so
         // the normalised input itself is K and V of the core: ONE projection GEMM (q' = M h + cq) instead of three, no V^T tensor, and proj_out runs on Wvp.
         Tens qf, o;
@@ -396,7 +399,7 @@ int run_attn(Ctx& c, const AttnW& w, const Tens& x, Tens* out, const FinReq* nex
         // WDM_ATTN_FUSED=3: q' = Mq h + cq as phase 0 of the core (attn_fused_kernel.h: QPROJ) -- same MFMA sequence and rounding as the GEMM it replaces, hence the same bits
         const bool q_in = proj_in && env_cfg().attn_fused >= 3 && w.qf.b != nullptr;
         AttnOperands in;
-        in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1;
+        in.k = hn.p; in.k_ld = hn.xs; in.v = hn.p; in.v_ld = hn.xs; in.v_tok = 1; in.bdiag = bdiag ? 1 : 0;
         if (q_in) {
             const bool sm = env_cfg().attn_sm && w.qf.w_sm != nullptr;
             in.qw = sm ? w.qf.w_sm : w.qf.w; in.qw_slab = sm ? w.qf.rows_pad * 32 : 0;

@@ -213,6 +213,7 @@ struct AttnOperands {
     // folded AttnBlock with proj_out fused (C <= 512): the query projection inside the kernel (attn_fused_kernel.h: QPROJ) -- q is then null and qw / qbias are the
     // folded [C][qw_ld] 16-bit matrix Wk^T Wq and its fp32 bias Wk^T bq
     const void* qw = nullptr; const float* qbias = nullptr; int qw_ld = 0; size_t qw_bytes = 0;
+    int bdiag = 0;       // 1: N = 64 tokens per image (8 x 8 maps): four images share a 256-row "image" of the kernel, attention stays inside each (attn_fused_kernel.h)
     int qw_slab = 0;     // 0: qw is the plain [C][qw_ld] matrix; else it is the slab-major copy [C / 32][rows][32] and this the elements between slabs (rows x 32)
 };
 // vbias != nullptr: V was computed without the v bias, which is added to the output instead
