@@ -34,9 +34,29 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 # stays the nominal figure the contract names; `roofline.sustained` prices the same achieved rate against this one.
 MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS = 1845.0
 # ... and when every MFMA's operands are fresh ds_read_b128 fragments of random data in LDS (0.375-0.5 reads per MFMA, 8-16 waves per CU, no barriers, no DMA, no
-# global traffic: the same tool's LDS-fed mode, profiles/r05_mfma_power_ldsfed.log -- 1 420 ... 1 470 TFLOP/s; 1 950 ... 2 165 on zeros): the ceiling of ANY LDS-fed
-# 16-bit MFMA loop on this board, which is what a convolution kernel is.
+# global traffic: the same tool's LDS-fed mode, profiles/r05_mfma_power_ldsfed.log, r05_mfma_power_probe.log -- 1 420 ... 1 610 TFLOP/s by box; 1 950 ... 2 165 on zeros): the ceiling of ANY LDS-fed
+# 16-bit MFMA loop on this board, which is what a convolution kernel is.  (A constant of the board CLASS: measure_board_roofs() below measures the board at hand.)
 MFMA_16BIT_LDS_FED_RANDOM_TFLOPS = 1450.0
+
+
+def measure_board_roofs():
+    """What this board sustains right now: tools/abl_mfma_power (built by __graft_entry__.build() from tools/mfma_power_ubench.hip) held for 1.5 s per variant in a child
+    process.  {} when the binary is not there or fails (the constants above then stand alone)."""
+    import re
+    import subprocess
+    exe = os.path.join(REPO, "tools", "abl_mfma_power")
+    out = {}
+    if not os.path.isfile(exe):
+        return out
+    for mode in ("reg", "lds"):
+        try:
+            r = subprocess.run([exe], env=dict(os.environ, HOLD="1.5", MODE=mode), capture_output=True, text=True, timeout=60)
+            m = re.search(r"([0-9.]+) TFLOP/s", r.stdout)
+            if r.returncode == 0 and m:
+                out[mode] = float(m.group(1))
+        except Exception:                                   # noqa: BLE001  (calibration only: never takes the headline down)
+            pass
+    return out
 
 
 def log(*a):
@@ -261,12 +281,19 @@ def main():
                     "all_conv_tflops": round(sum(e["flops"] for e in rep) / tot_ms / 1e9, 2),
                     "conv_ms_per_pass": round(tot_ms, 2)}
         if args.dtype in ("bf16", "f16"):
+            live = measure_board_roofs()          # this very board, right behind the timed passes (the boxes of the pool differ by ~10 % in what their power limit gives)
             roofline["sustained"] = {"peak": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, 4),
                                      "what": "register-resident 16x16x32 MFMA loop on random 16-bit operands, measured on this board class (power-limited; 2476 on zeros): "
                                              "profiles/r05_mfma_power_ubench.log",
                                      "lds_fed": {"peak": MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, 4),
                                                  "what": "the same loop with every operand a fresh ds_read_b128 fragment of random data in LDS (0.375-0.5 reads per MFMA, "
-                                                         "no barriers / DMA / global traffic): 1420-1470 measured, profiles/r05_mfma_power_ldsfed.log"}}
+                                                         "no barriers / DMA / global traffic): 1420-1610 measured by box, profiles/r05_mfma_power_ldsfed.log, r05_mfma_power_probe.log"}}
+            if live:
+                roofline["sustained"]["this_board"] = {
+                    "register_resident": live.get("reg"), "lds_fed": live.get("lds"), "unit": "TFLOP/s",
+                    "frac_of_lds_fed": round(ach / live["lds"], 4) if live.get("lds") else None,
+                    "what": "tools/mfma_power_ubench.hip held for 1.5 s each on THIS board right after the timed passes (random bf16 operands): the MFMA-only loop and the "
+                            "LDS-fed loop (0.375 ds_read_b128 per MFMA, nothing else); frac_of_lds_fed = achieved / the LDS-fed figure"}
         # Since round 3 the 3x3 stride-1 convs of the 16-pixel-multiple maps -- ONE kernel name until round 2 -- run as three tilings / schedules of the
         # same LDS-DMA design (256 x 128 persistent on the 64 x 64 maps, 256 x 128 on 16 x 16, 256 x 256 on 32 x 32), so "the dominant kernel" above is
         # the largest of the three; the family figure is the like-for-like successor of round 2's single-kernel number.

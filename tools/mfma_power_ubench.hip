@@ -138,6 +138,22 @@ static void run(const uint4* src, const char* what) {
     printf("%-28s best %7.3f ms  %6.0f TFLOP/s   mean %7.3f ms %6.0f TFLOP/s\n", what, best, flop / best / 1e9, sum / 5, flop / (sum / 5) / 1e9);
 }
 
+// HOLD=<seconds> MODE=reg|lds : one variant back to back for that long (scripts/mfma_power_probe.sh samples socket power and shader clock beside it)
+template <class F>
+static void hold(F launch, double flop_per_launch, double seconds, const char* what) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    launch(); CK(hipDeviceSynchronize());
+    int n = 0; float total = 0.f;
+    while (total < seconds * 1e3f) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total += ms; n += 20;
+    }
+    printf("%s: %d launches in %.2f s  %6.0f TFLOP/s\n", what, n, total / 1e3, flop_per_launch * n / total / 1e9);
+}
+
 int main() {
     const bool zero = getenv("ZERO") != nullptr;
     std::vector<unsigned short> h((size_t)(1 << 20) * 8);
@@ -147,6 +163,16 @@ int main() {
         v = zero ? 0 : (unsigned short)(sign | (14 + (rand() & 1)) << 10 | mant);       // fp16: exponent 14 / 15 (0.5 ... 2); as bf16 the same bits are tiny normal numbers with random mantissas
     }
     uint4* src; CK(hipMalloc(&src, h.size() * 2)); CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    if (getenv("HOLD")) {
+        const double sec = atof(getenv("HOLD"));
+        const char* mode = getenv("MODE") ? getenv("MODE") : "lds";
+        if (mode[0] == 'r') hold([&] { hipLaunchKernelGGL(k<0>, dim3(512), dim3(512), 0, 0, src, 4096, (float*)nullptr); }, 512.0 * 8 * 4096 * 64 * 2.0 * 16 * 16 * 32, sec, "register-resident 16x16x32 bf16");
+        else {
+            CK(hipFuncSetAttribute((const void*)kl<4, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            hold([&] { hipLaunchKernelGGL((kl<4, 8, false>), dim3(512), dim3(512), 65536, 0, src, 2048, (float*)nullptr); }, 512.0 * 8 * 2048 * 32 * 2.0 * 16 * 16 * 32, sec, "LDS-fed 16x16x32 bf16, 0.375 reads per MFMA");
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0>(src, "16x16x32 bf16");
         run<1>(src, "32x32x16 bf16");
