@@ -66,3 +66,8 @@ def test_bench_parity_mode_is_the_fastest_conformant_mode():
     assert pm["dtype"] == "f16" and pm["rel_linf_vs_f32_full_length"] <= 1e-3 and pm["value"] > pm["f32x3"]["value"] > pm["exact_f32"]["value"]
     assert pm["f32x3"]["rel_linf_vs_f32_full_length"] <= 1e-4 and pm["roofline"]["peak"] == 2500.0
     assert line["dtype"] == "bf16" and line["roofline"]["sustained"]["peak"] == 1845.0 and line["roofline"]["frac"] < line["roofline"]["sustained"]["frac"]
+    # the board's own roofs, measured by the bench behind its timed passes (tools/abl_mfma_power, built by __graft_entry__.build()): the LDS-fed loop sits below the
+    # register-resident one, both below the nominal peak, and the kernel below both
+    tb = line["roofline"]["sustained"].get("this_board")
+    if os.path.isfile(os.path.join(repo, "tools", "abl_mfma_power")):
+        assert tb and 900.0 < tb["lds_fed"] < tb["register_resident"] < 2500.0 and 0.0 < tb["frac_of_lds_fed"] < 1.0, tb
