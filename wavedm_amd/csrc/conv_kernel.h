@@ -300,9 +300,19 @@ __device__ __forceinline__ uint4 gn_silu_unit(const uint4& u, const float* sc, c
     for (int e = 0; e < VEC; e += 2) {
         const f32x2 x = {f[e], f[e + 1]}, s2 = {sc[e], sc[e + 1]}, h2 = {sh[e], sh[e + 1]};
         const f32x2 t = x * s2 + h2;
+#if defined(WDM_SILU_ABL) && WDM_SILU_ABL == 1      // tools: the transform without its four transcendentals per pair (timing only, wrong values)
+        f32x2 d = t;
+        d = d + 1.0f;
+        const f32x2 r = d;
+#elif defined(WDM_SILU_ABL) && WDM_SILU_ABL == 2    // tools: without the two reciprocals
+        f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        d = d + 1.0f;
+        const f32x2 r = d;
+#else
         f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
         d = d + 1.0f;
         const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+#endif
         const f32x2 y = (t * -0.6931471805599453f) * r;
         f[e] = y.x; f[e + 1] = y.y;
     }
