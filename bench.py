@@ -101,7 +101,11 @@ def main():
     ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c4"],
                     help="c1: BASELINE configs[1] (default, the headline metric); c2: 128x128 patches, batch 256; "
                          "c4: whole 480x720 images, 45 stitched patches each, 50 DDIM steps (informational extra runs)")
-    ap.add_argument("--images-per-call", type=int, default=1, help="c4 only: loader items restored per sampler call (SURVEY.md §8f-2)")
+    ap.add_argument("--images-per-call", type=int, default=0, help="c4 only: loader items restored per sampler call (SURVEY.md §8f-2); 0 = restore()'s own default "
+                                                                   "(auto: as many same-sized images as fill the UNet calls)")
+    ap.add_argument("--patch-sharded", action="store_true", help="c4 with N > 1 only: the latency form of SURVEY.md §8e-ii -- every rank works on the SAME image, its 45 patches "
+                                                                 "split 6/6/6/6/6/5/5/5 over 8 ranks, one all-reduce(sum) of 2 x 3 x 120 x 180 floats per DDIM step")
+    ap.add_argument("--full-length", action="store_true", help="c4 only: run the 4 steps restore() does not read (args.early_stop = False, the reference's step count)")
     ap.add_argument("--max-batch", type=int, default=0, help="UNet call batch cap (default max(batch, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs of the default N=1 run (configs[2], configs[4]) AND the parity modes")
@@ -129,6 +133,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.ddim_steps < 5:
+        fail(f"--ddim-steps {args.ddim_steps}: the restored image is built from x0_preds[-5] (restoration.py:108), so a run needs at least 5 steps", args.gpus, rank)
     if world != args.gpus:
         fail(f"--gpus {args.gpus} but WORLD_SIZE={world}: start as `python bench.py --gpus {args.gpus}` (self-launching) or under "
              f"torch.distributed.run --nproc-per-node {args.gpus}", args.gpus, rank)
@@ -158,17 +164,19 @@ def main():
         # per GPU: one image per sampler call at N = 1 (the reference's loop shape); with N > 1 the throughput form of §8f-2 --
         # 8 images per GPU in ONE stitched sampler call, UNet batches of 128 (5.2 vs 3.8 img/s per GPU)
         multi = args.gpus > 1
-        if args.batch == 64:
-            args.batch = 8 if multi else 1
-        if multi and args.images_per_call == 1:
-            args.images_per_call = 8
-        if multi and not args.max_batch:
+        if args.patch_sharded:
+            if not multi:
+                fail("--patch-sharded needs --gpus > 1", args.gpus, rank)
+            args.batch, args.images_per_call = (1 if args.batch == 64 else args.batch), 1
+        elif args.batch == 64:
+            args.batch = 8
+        if not args.max_batch:
             args.max_batch = 128
     cfg = P.raindrop_wavelet_config(image_size=128 if args.workload == "c2" else 64)
     cfg.device = dev
     a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_dev, image_folder="/tmp/wdm",
                         test_set="raindrop", grid_r=16, max_batch=args.max_batch or max(args.batch, 64),
-                        images_per_call=args.images_per_call)
+                        images_per_call=args.images_per_call or None, early_stop=not args.full_length)
     t0 = time.time()
     d = wavedm_amd.DenoisingDiffusion_Wavelet(a, cfg, generator=lambda x: x, dtype=args.dtype)   # HFRM: identity stand-in
     sd = None
@@ -192,16 +200,19 @@ def main():
     B = args.batch
     if args.workload == "c4":
         # whole images: DWT -> 45 overlapping 64x64 patches (r = 16) per image through the stitched sampler -> IDWT
-        g = torch.Generator().manual_seed(61 + rank)
+        g = torch.Generator().manual_seed(61 + (0 if args.patch_sharded else rank))      # patch-sharded: every rank holds the same image
         imgs = [torch.rand(1, 6, 480, 720, generator=g) for _ in range(B)]
         restorer = wavedm_amd.DiffusiveRestoration(d, a, cfg, save_images=False)
+        if args.patch_sharded:
+            d.patch_group = True                                  # sampling.ddim_sample: this rank's slice of the patch list, one all-reduce per step
+            args.no_roofline = True                               # (the roofline leg is one more pass on rank 0 ALONE: it would wait for the others' all-reduce)
         loader = [(im, f"img{k}", torch.zeros(1)) for k, im in enumerate(imgs)]
 
         def one_pass():
             import contextlib, io
             with contextlib.redirect_stdout(io.StringIO()):
                 outs, _ = restorer.restore(loader, validation="raindrop", r=16)
-            return outs[-1], None, None
+            return torch.cat(outs), None, None
     else:
         rainy, x_T = P.synthetic_batch(B, patch_px=4 * cfg.data.image_size, seed=61 + rank)
         rainy, x_T = rainy.to(dev), x_T.to(dev)
@@ -273,7 +284,8 @@ def main():
             except Exception:
                 continue
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC passes, {traffic_src})",
+                    "traffic": traffic, "traffic_source": "quoted" if traffic is not None else None,
+                    "traffic_unit": f"bytes/launch; QUOTED from the committed PMC summary {traffic_src} (rocprofv3 --pmc needs passes of its own: not measured in this run)",
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
@@ -282,18 +294,20 @@ def main():
                     "conv_ms_per_pass": round(tot_ms, 2)}
         if args.dtype in ("bf16", "f16"):
             live = measure_board_roofs()          # this very board, right behind the timed passes (the boxes of the pool differ by ~10 % in what their power limit gives)
-            roofline["sustained"] = {"peak": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, 4),
-                                     "what": "register-resident 16x16x32 MFMA loop on random 16-bit operands, measured on this board class (power-limited; 2476 on zeros): "
-                                             "profiles/r05_mfma_power_ubench.log",
-                                     "lds_fed": {"peak": MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, 4),
-                                                 "what": "the same loop with every operand a fresh ds_read_b128 fragment of random data in LDS (0.375-0.5 reads per MFMA, "
-                                                         "no barriers / DMA / global traffic): 1420-1610 measured by box, profiles/r05_mfma_power_ldsfed.log, r05_mfma_power_probe.log"}}
-            if live:
-                roofline["sustained"]["this_board"] = {
-                    "register_resident": live.get("reg"), "lds_fed": live.get("lds"), "unit": "TFLOP/s",
-                    "frac_of_lds_fed": round(ach / live["lds"], 4) if live.get("lds") else None,
-                    "what": "tools/mfma_power_ubench.hip held for 1.5 s each on THIS board right after the timed passes (random bf16 operands): the MFMA-only loop and the "
-                            "LDS-fed loop (0.375 ds_read_b128 per MFMA, nothing else); frac_of_lds_fed = achieved / the LDS-fed figure"}
+            if live.get("reg") and live.get("lds"):
+                # every fraction on the line belongs to the timed box: the board-class constants are named, not priced against
+                roofline["sustained"] = {"this_board": {
+                    "register_resident": live["reg"], "lds_fed": live["lds"], "unit": "TFLOP/s",
+                    "frac_of_register_resident": round(ach / live["reg"], 4), "frac_of_lds_fed": round(ach / live["lds"], 4),
+                    "what": "tools/mfma_power_ubench.hip held for 1.5 s each on THIS board right after the timed passes (random bf16 operands): the MFMA-only register-resident "
+                            "16x16x32 loop and the LDS-fed loop (0.375 ds_read_b128 per MFMA, nothing else); frac_* = achieved / that figure"},
+                    "board_class": {"register_resident": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "lds_fed": MFMA_16BIT_LDS_FED_RANDOM_TFLOPS,
+                                    "what": "the same two loops as measured on other boards of the pool (profiles/r05_mfma_power_ubench.log, r05_mfma_power_ldsfed.log): context, no fraction taken"}}
+            else:
+                roofline["sustained"] = {"peak": MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_SUSTAINED_RANDOM_TFLOPS, 4),
+                                         "what": "calibration binary tools/abl_mfma_power missing or failed: board-CLASS constants (register-resident 16x16x32 MFMA loop on random 16-bit "
+                                                 "operands, profiles/r05_mfma_power_ubench.log), not this board's",
+                                         "lds_fed": {"peak": MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, "frac": round(ach / MFMA_16BIT_LDS_FED_RANDOM_TFLOPS, 4)}}
         # Since round 3 the 3x3 stride-1 convs of the 16-pixel-multiple maps -- ONE kernel name until round 2 -- run as three tilings / schedules of the
         # same LDS-DMA design (256 x 128 persistent on the 64 x 64 maps, 256 x 128 on 16 x 16, 256 x 256 on 32 x 32), so "the dominant kernel" above is
         # the largest of the three; the family figure is the like-for-like successor of round 2's single-kernel number.
@@ -386,77 +400,81 @@ def main():
             return fl
 
         if not args.no_extras:
-            # configs[4] per GPU: 8 whole 480x720 images per sampler call, 45 stitched 64x64 patches each, 50 DDIM steps
-            a4 = SimpleNamespace(**vars(a))
-            a4.sampling_timesteps, a4.images_per_call, a4.max_batch = 50, 8, 128
-            d.args = a4
-            g4 = torch.Generator().manual_seed(4)
-            loader4 = [(torch.rand(1, 6, 480, 720, generator=g4), f"img{k}", torch.zeros(1)) for k in range(8)]
-            rest4 = wavedm_amd.DiffusiveRestoration(d, a4, cfg, save_images=False)
-
-            def pass_c4():
-                with contextlib.redirect_stdout(io.StringIO()):
-                    rest4.restore(loader4, validation="raindrop", r=16)
-            t4 = timed(pass_c4)
-            sp4 = spread()
-            a4.sampling_timesteps = 5
-            fl4 = conv_flops_per_pass(pass_c4) * 10
-            extras.append({"workload": "BASELINE.json configs[4] per GPU: 8 whole 480x720 images, 45 stitched 64x64 patches each (r = 16), 50 DDIM steps, "
-                                       "8 images per sampler call", "value": round(8 / t4, 3), "unit": "img/s", "ms_per_step": round(t4 * 1e3, 1),
-                           "steps": 3, "warmup": 1, "spread": sp4, "conv_tflops": round(fl4 / t4 / 1e12, 1)})
-            d.args = a
-            log(f"[bench] extra configs[4]: {8 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per 8 images)")
-            del rest4, loader4
-            # configs[4] through the WHOLE restore() pipeline: PNG files on disk -> wavedm_amd.datasets.RainDrop loader (PIL decode +
-            # LANCZOS resizes, pinned DataLoader) -> device HFRM with procedural weights (models/arch.py, once per image) -> DWT -> stitched 50-step sampler ->
-            # IDWT -> three PSNRs on the device -> 8-bit conversion on the device + seven PNGs per image through the asynchronous writer (flushed inside the clock)
+            # configs[4] per GPU through the reference's own call surface, DiffusiveRestoration.restore() with ITS defaults (early stop at x0_preds[-5], automatic
+            # images per sampler call, groups pipelined two deep), 32 whole 480x720 images = 4 groups of 8, at 50 DDIM steps (configs[4]) and at the reference's
+            # default 25 (eval_diffusion.py:26).  Two legs per step count:
+            #   sampler-only   : the 32 images already tensors in host memory, identity HFRM stand-in, no PNGs
+            #   whole pipeline : 32 PNG pairs on disk -> wavedm_amd.datasets.RainDrop loader (PIL decode + LANCZOS resizes, pinned DataLoader built OUTSIDE the clock,
+            #                    its workers start inside) -> device HFRM with procedural weights (models/arch.py, once per image) -> DWT -> stitched sampler -> IDWT ->
+            #                    three PSNRs on the device -> 8-bit conversion on the device + seven PNGs per image through the asynchronous writer, flushed inside the clock
             try:
                 import tempfile, shutil, copy
                 import numpy as np
                 from PIL import Image
                 from wavedm_amd.datasets import RainDrop
+                N4 = 32
                 root = tempfile.mkdtemp(prefix="wdm_c4_")
                 rng = np.random.default_rng(44)
                 for sub_ in ("raindrop_test", "train"):
                     for leaf in ("input", "gt"):
                         os.makedirs(os.path.join(root, "raindrop", sub_, leaf))
-                for k in range(8):
+                for k in range(N4):
                     clean = rng.integers(0, 256, (480, 720, 3), dtype=np.uint8)
                     drop = np.clip(clean.astype(np.int16) + rng.integers(-40, 41, (480, 720, 3)), 0, 255).astype(np.uint8)
-                    Image.fromarray(drop).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"))
-                    Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"))
+                    Image.fromarray(drop).save(os.path.join(root, "raindrop", "raindrop_test", "input", f"{k}_rain.png"), compress_level=1)
+                    Image.fromarray(clean).save(os.path.join(root, "raindrop", "raindrop_test", "gt", f"{k}_clean.png"), compress_level=1)
                 cfg4 = copy.deepcopy(cfg)
                 cfg4.device = dev
                 cfg4.data.data_dir = root
-                cfg4.data.num_workers = 4
-                a5 = SimpleNamespace(**vars(a))
-                a5.sampling_timesteps, a5.images_per_call, a5.max_batch, a5.world_size, a5.rank = 50, 8, 128, 1, 0
-                a5.image_folder = os.path.join(root, "out")
-                d.args = a5
+                cfg4.data.num_workers = 8
+                g4 = torch.Generator().manual_seed(4)
+                loader4 = [(torch.rand(1, 6, 480, 720, generator=g4), f"img{k}", torch.zeros(1)) for k in range(N4)]
                 ident = d.generator
-                d.generator = d._make_generator("procedural", args.dtype)
-                rest5 = wavedm_amd.DiffusiveRestoration(d, a5, cfg4, save_images=True)
+                hfrm = d._make_generator("procedural", args.dtype)
+                for S4 in (50, 25):
+                    a4 = SimpleNamespace(**vars(a))
+                    a4.sampling_timesteps, a4.images_per_call, a4.max_batch, a4.early_stop, a4.world_size, a4.rank = S4, None, 128, True, 1, 0
+                    a4.image_folder = os.path.join(root, f"out{S4}")
+                    d.args = a4
+                    d.generator = ident
+                    rest4 = wavedm_amd.DiffusiveRestoration(d, a4, cfg, save_images=False)
+                    per_call = rest4.images_per_call_for(120, 180, 16)
 
-                def pass_c4_real():
-                    with contextlib.redirect_stdout(io.StringIO()):
-                        _, val_loader = RainDrop(a5, cfg4).get_loaders(parse_patches=False, validation="raindrop")
-                        rest5.restore(val_loader, validation="raindrop", r=16)          # ends with writer.flush(): every PNG is on disk
-                t5 = timed(pass_c4_real)
-                n_png = len(os.listdir(os.path.join(a5.image_folder, cfg4.data.dataset, "raindrop")))
-                extras.append({"workload": "BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: 8 PNG pairs on disk -> RainDrop loader (PIL, 4 workers) -> device HFRM "
-                                           "(procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, 50 DDIM steps, 8 images per sampler call -> "
-                                           "IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
-                               "value": round(8 / t5, 3), "unit": "img/s", "ms_per_step": round(t5 * 1e3, 1), "steps": 3, "warmup": 1, "spread": spread(), "pngs_written": n_png,
-                               "vs_identity_standin_leg": round(t4 / t5, 3)})
-                log(f"[bench] extra configs[4] whole pipeline (real HFRM, loader, PNGs): {8 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per 8 images, {n_png} PNGs)")
-                rest5.writer.close()
+                    def pass_c4():
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            rest4.restore(loader4, validation="raindrop", r=16)
+                    t4 = timed(pass_c4)
+                    sp4 = spread()
+                    base = {"images": N4, "ddim_steps": S4, "steps_run": S4 - 4, "images_per_sampler_call": per_call, "unet_call_cap": 128, "unit": "img/s", "steps": 3, "warmup": 1}
+                    extras.append(dict(base, workload=f"BASELINE.json configs[4] per GPU, SAMPLER-ONLY leg of DiffusiveRestoration.restore(): {N4} whole 480x720 images in host memory, 45 "
+                                                      f"stitched 64x64 patches each (r = 16), {S4} DDIM steps (early stop at x0_preds[-5]: {S4 - 4} run), identity HFRM stand-in, no PNGs",
+                                       value=round(N4 / t4, 3), ms_per_step=round(t4 * 1e3, 1), spread=sp4))
+                    log(f"[bench] extra configs[4] S={S4} sampler-only: {N4 / t4:.2f} img/s ({t4 * 1e3:.0f} ms per {N4} images, {per_call} per call)")
+                    d.generator = hfrm
+                    rest5 = wavedm_amd.DiffusiveRestoration(d, a4, cfg4, save_images=True)
+                    _, val_loader = RainDrop(a4, cfg4).get_loaders(parse_patches=False, validation="raindrop")      # built once, outside the clock
+
+                    def pass_c4_real():
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            rest5.restore(val_loader, validation="raindrop", r=16)          # ends with writer.flush(): every PNG is on disk
+                    t5 = timed(pass_c4_real)
+                    n_png = len(os.listdir(os.path.join(a4.image_folder, cfg4.data.dataset, "raindrop")))
+                    extras.append(dict(base, workload=f"BASELINE.json configs[4] per GPU, WHOLE restore() pipeline: {N4} PNG pairs on disk -> RainDrop loader (PIL, 8 workers, built outside "
+                                                      f"the clock) -> device HFRM (procedural weights, 15.9 M parameters) -> DWT -> 45 stitched 64x64 patches per image, {S4} DDIM steps (early "
+                                                      f"stop: {S4 - 4} run) -> IDWT -> PSNR x3 on the device -> u8 + 7 PNGs per image (async writer, flushed inside the clock)",
+                                       value=round(N4 / t5, 3), ms_per_step=round(t5 * 1e3, 1), spread=spread(), pngs_written=n_png, pipeline_over_sampler_only=round(t4 / t5, 3)))
+                    log(f"[bench] extra configs[4] S={S4} whole pipeline (real HFRM, loader, PNGs): {N4 / t5:.2f} img/s ({t5 * 1e3:.0f} ms per {N4} images, {n_png} PNGs) = "
+                        f"{t4 / t5:.3f} of sampler-only")
+                    rest5.writer.close()
+                    del rest4, rest5, val_loader
                 d.generator = ident
                 d.args = a
-                del rest5
+                del loader4, hfrm
                 shutil.rmtree(root, ignore_errors=True)
             except Exception as e:                                      # the informational leg must not take the headline down with it
-                log(f"[bench] extra configs[4] whole pipeline FAILED: {type(e).__name__}: {e}")
-                extras.append({"workload": "BASELINE.json configs[4] whole restore() pipeline", "value": None, "error": f"{type(e).__name__}: {e}"})
+                import traceback
+                log(f"[bench] extra configs[4] FAILED: {type(e).__name__}: {e}\n{traceback.format_exc()}")
+                extras.append({"workload": "BASELINE.json configs[4] restore() legs", "value": None, "error": f"{type(e).__name__}: {e}"})
                 d.args = a
             # configs[2]: 128x128 wavelet-domain patches, batch 256, 100 steps (its own 163 M-parameter UNet: attention sits one level deeper)
             cfg2 = P.raindrop_wavelet_config(image_size=128)
@@ -575,7 +593,8 @@ def main():
         a.sampling_timesteps = args.ddim_steps
 
     if rank == 0:
-        total_imgs = B * world * args.steps
+        sharded_one = args.workload == "c4" and args.patch_sharded                   # every rank worked on the SAME B images
+        total_imgs = B * (1 if sharded_one else world) * args.steps
         res = {
             "metric": f"restored images/sec, raindrop 64x64 patches, {args.ddim_steps}-step DDIM" if args.workload == "c1" else
                       f"restored images/sec, workload {args.workload} (informational, not the headline metric)",
@@ -594,7 +613,8 @@ def main():
                                     f"DWT + UNet x{args.ddim_steps} + IDWT (BASELINE.json configs[1]{' x N, configs[3]' if world > 1 else ''})") if args.workload == "c1"
                        else (f"raindrop_wavelet 128x128 patches, batch {B}/GPU, {args.ddim_steps} DDIM steps (BASELINE.json configs[2])" if args.workload == "c2"
                              else f"{B} full 480x720 image(s)/GPU, 45 stitched 64x64 patches each, {args.ddim_steps} DDIM steps (BASELINE.json configs[4])"),
-                       "global_batch": B * world, "ddim_steps": args.ddim_steps, "parallelism": f"image-sharded x{world}",
+                       "global_batch": B * (1 if sharded_one else world), "ddim_steps": args.ddim_steps,
+                       "parallelism": f"patch-sharded x{world} (one all-reduce per DDIM step)" if sharded_one else f"image-sharded x{world}",
                        "outputs_finite": finite},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -604,7 +624,11 @@ def main():
         if extras:
             res["extras"] = extras
         if world > 1:
+            if sharded_one:
+                res["scaling"] = "strong"                                            # the same image(s) whatever N is
             res["rccl"] = {"rccl_ranks": world, "backend": backend, "weight_broadcast_s": round(bcast_s, 4) if bcast_s is not None else None,
+                           **({"patch_shards": [parallel.shard_range(45 * B, r_, world)[1] - parallel.shard_range(45 * B, r_, world)[0] for r_ in range(world)],
+                               "allreduce_bytes_per_step": 2 * B * 3 * 120 * 180 * 4} if sharded_one else {}),
                            "rank_elapsed_s_min": round(min(rank_elapsed), 4), "rank_elapsed_s_max": round(max(rank_elapsed), 4)}
         if cpu:
             res["speedup_vs_cpu"] = round(res["value"] / cpu["value"], 1)

@@ -100,6 +100,14 @@ int wdm_ddim_update(wdm_handle* h, const float* eps, const int32_t* patches, int
                     int nimg, int H, int W, float sqrt_1m_at, float sqrt_at, float sqrt_at_next, float c2,
                     float* x0_out, float* x_next_out, void* stream);
 
+/* wdm_ddim_update_eta: the same scatter-mean and x0, with the stochastic term of models/ddm_wavelet.py:500-502 (eta != 0; the reference's
+ * own callers pass eta = 0, ddm_wavelet.py:302):  c1 = eta*sqrt((1 - at/at_next)(1 - at_next)/(1 - at)), c2 = sqrt((1 - at_next) - c1^2) -- both
+ * computed by the caller in fp32 --  x_next = sqrt_at_next*x0 + c1*noise + c2*eps, summed left to right like the reference's expression.
+ *   noise (NIMG, 3, H, W) f32 : the caller's randn_like(x) draw of this step */
+int wdm_ddim_update_eta(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, const float* x_t,
+                        int nimg, int H, int W, float sqrt_1m_at, float sqrt_at, float sqrt_at_next, float c1, float c2,
+                        const float* noise, float* x0_out, float* x_next_out, void* stream);
+
 /* Patch-sharded single image (no reference counterpart -- its eval is single-GPU): every rank runs the UNet
  * on ITS patches only.  wdm_patch_accumulate writes the rank's partial sums (NIMG*3*H*W floats) followed by its partial overlap
  * counts (same size) into acc_cnt, the caller all-reduces (sum) that ONE buffer over RCCL, and wdm_ddim_from_sums divides and

@@ -321,8 +321,9 @@ def overlap_count_mask(h, w, p, corners) -> torch.Tensor:
 
 
 def ddim_overlapping(sd, config, x, x_cond, x_other, corners, p, sampling_timesteps,
-                     betas=None, model=None, chunk=8):
-    """ddm_wavelet.py:437-506 with eta=0, begin_from_noise=True; use_other=False <=> x_other is None (:471-478).
+                     betas=None, model=None, chunk=8, eta=0.0, noises=None):
+    """ddm_wavelet.py:437-506, begin_from_noise=True; use_other=False <=> x_other is None (:471-478).
+    eta != 0 (:500-502): `noises` is the list of the per-step `torch.randn_like(x)` draws (None: drawn here from torch's default generator, like the reference).
 
     x: (1,3,H,W) start noise, x_cond: (1,48,H,W), x_other: (1,45,H,W) or None.
     Returns (xs, x0_preds) lists like the reference (len S+1 and S).
@@ -358,8 +359,14 @@ def ddim_overlapping(sd, config, x, x_cond, x_other, corners, p, sampling_timest
             et = acc / mask
             x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
             x0_preds.append(x0_t)
-            c2 = (1 - at_next).sqrt()                      # c1 = 0 for eta = 0
-            xs.append(at_next.sqrt() * x0_t + c2 * et)
+            if eta == 0.0:
+                c2 = (1 - at_next).sqrt()                  # c1 = 0 for eta = 0
+                xs.append(at_next.sqrt() * x0_t + c2 * et)
+            else:                                          # ddm_wavelet.py:500-502
+                c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+                c2 = ((1 - at_next) - c1 ** 2).sqrt()
+                z = torch.randn_like(x) if noises is None else noises[len(x0_preds) - 1]
+                xs.append(at_next.sqrt() * x0_t + c1 * z + c2 * et)
     return xs, x0_preds
 
 

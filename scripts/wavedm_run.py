@@ -8,7 +8,7 @@
 `eval` = eval_diffusion.py (DiffusiveRestoration.restore over the validation loader), `train` = train_diffusion.py (diffusion.train).
 --config is a file name under ./configs or a path.  Under torchrun every rank restores its share of the validation images (the
 loaders use a DistributedSampler) and rank 0 prints the PSNR over all of them; training all-reduces gradients over RCCL.
-Extras: --dtype {bf16,f32}, --images_per_call N (eval: images per sampler call), --hfrm_ckpt PATH, --max_steps N (train)."""
+Extras: --dtype {f16,bf16,f32x3,f32} (default: f16 when the checkpoint fits fp16, else bf16 with a warning), --images_per_call N (eval: images per sampler call), --hfrm_ckpt PATH, --max_steps N (train)."""
 import argparse
 import os
 import random
@@ -35,7 +35,7 @@ def parse(argv=None):
     ap.add_argument("--image_folder", default="results/images", help="where restored images / validation sheets are written")
     ap.add_argument("--seed", type=int, default=61)
     ap.add_argument("--ema", action="store_true", help="eval: load the EMA weights of the checkpoint")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["f16", "bf16", "f32x3", "f32"])
     ap.add_argument("--images_per_call", type=int, default=1)
     ap.add_argument("--hfrm_ckpt", default=None)
     ap.add_argument("--max_steps", type=int, default=None)

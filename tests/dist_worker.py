@@ -26,6 +26,20 @@ def main(out_path):
     else:
         dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("WDM_TEST_MODE") == "patch8":
+        # one 480x720 image, its 45 patches sharded over the ranks inside DiffusiveRestoration.restore() (tests/test_gpu_dist.py)
+        from test_gpu_dist import patch8_setup
+        d, args, img = patch8_setup(dev)
+        d.patch_group = True
+        rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
+        torch.manual_seed(77 + 1000 * rank)                         # ranks draw DIFFERENT start noise: the sampler must spread rank 0's
+        outs, psnr = rest.restore([(img, ("one",), torch.zeros(1))], validation="raindrop", r=16)
+        shards = [parallel.shard_range(45, r_, world)[1] - parallel.shard_range(45, r_, world)[0] for r_ in range(world)]
+        if rank == 0:
+            torch.save({"out": outs[0].cpu(), "psnr": psnr[0], "world": world, "shards": shards}, out_path)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     cfg = P.reduced_config()
     cfg.device = dev
     args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=dev.index, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=4)

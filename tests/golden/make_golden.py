@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--only-variants", action="store_true", help="regenerate variants.npz only")
     ap.add_argument("--only-config", action="store_true", help="regenerate config.npz only")
     ap.add_argument("--only-global", action="store_true", help="regenerate global.npz only")
+    ap.add_argument("--only-eta", action="store_true", help="regenerate eta.npz only")
+    ap.add_argument("--only-timing", action="store_true", help="time the reference against the oracle on BASELINE configs[0] only (oracle_timing.json)")
     args = ap.parse_args()
 
     install_stubs()
@@ -292,6 +294,88 @@ def main():
                             n_keys=np.array(sum(len(v) for v in ref_cfg.values())), sections=np.array(sorted(ref_cfg)))
         print(f"  procedural config == reference YAML ({sum(len(v) for v in ref_cfg.values())} keys)")
 
+    # ------------------------------------------------------------------ eta != 0 (ddm_wavelet.py:500-502): the stochastic term of generalized_steps_overlapping
+    def golden_eta():
+        print("[eta]")
+        c = P.reduced_config()
+        c.device = torch.device("cpu")
+        sd_e = P.procedural_state_dict(c)
+        net_e = RU.DiffusionUNet(c).eval()
+        net_e.load_state_dict(sd_e, strict=True)
+        d = object.__new__(DenoisingDiffusion_Wavelet)
+        d.config, d.device, d.model = c, torch.device("cpu"), net_e
+        d.betas = torch.from_numpy(get_beta_schedule(beta_schedule="linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+        d.num_timesteps = 1000
+        S, eta = 6, 0.5
+        xc, xT = seeded((1, 48, 24, 28), 810), seeded((1, 3, 24, 28), 811)
+        corners = O.grid_corners(24, 28, 16, 4)
+        seq = range(0, 1000, 1000 // S)
+        torch.manual_seed(812)
+        xs, x0p = d.generalized_steps_overlapping(xT, xc, seq, net_e, d.betas, eta=eta, corners=corners, p_size=16, x_other=xc[:, 3:], use_other=True)
+        torch.manual_seed(812)
+        noises = [torch.randn_like(xT) for _ in range(len(list(seq)))]      # the draws ddm_wavelet.py:502 made, in order
+        oxs, ox0 = O.ddim_overlapping(sd_e, c, xT, xc, xc[:, 3:], corners, 16, S, eta=eta, noises=noises)
+        assert len(xs) == len(oxs)
+        check("eta=0.5 xs[-1]", oxs[-1], xs[-1])
+        check("eta=0.5 x0_preds[-1]", ox0[-1], x0p[-1])
+        check("eta=0.5 xs[2]", oxs[2], xs[2])
+        np.savez_compressed(out("eta.npz"), eta=np.array(eta, dtype=np.float32), S=np.array(S, dtype=np.int32), x_T=xT.numpy(), x_cond=xc.numpy(),
+                            noises=torch.stack(noises).numpy(), xs_last=xs[-1].numpy(), x0_last=x0p[-1].numpy(), xs_2=xs[2].numpy())
+
+    # ------------------------------------------------------------------ the oracle stands in for the reference as the CPU baseline on the GPU box
+    # only if it runs the same work in the same time here -- config 0 (4 x 64 x 64, 10 DDIM steps, fp32, 8 threads), reference and oracle interleaved, best of 3
+    def golden_timing():
+        import json
+        import time
+        print("[timing]  reference vs oracle wall time on BASELINE configs[0] (156 M procedural weights)")
+        torch.set_num_threads(8)
+        c = P.raindrop_wavelet_config()
+        c.device = torch.device("cpu")
+        sd_f = P.procedural_state_dict(c, seed=61)
+        net_f = RU.DiffusionUNet(c).eval()
+        net_f.load_state_dict(sd_f, strict=True)
+        dec_ = WaveletTransform(scale=2, dec=True)
+        d = object.__new__(DenoisingDiffusion_Wavelet)
+        d.config, d.device, d.model = c, torch.device("cpu"), net_f
+        d.args = SimpleNamespace(sampling_timesteps=10, resume="", local_rank=0, image_folder="/tmp/x", test_set="raindrop", grid_r=16)
+        d.betas = torch.from_numpy(get_beta_schedule(beta_schedule="linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+        d.num_timesteps = 1000
+        rainy, x_T = P.synthetic_batch(4, patch_px=256, seed=61)
+        x_cond = dec_(2 * rainy - 1)
+        x_other = x_cond[:, 3:]
+
+        def run_ref():
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):            # (the reference prints one line per step)
+                return torch.cat([d.sample_image(x_cond[i:i + 1], x_T[i:i + 1], x_other=x_other[i:i + 1], last=False, patch_locs=[(0, 0)], patch_size=64,
+                                                 use_other=True)[0][-1] for i in range(4)])
+
+        def run_oracle():
+            return O.ddim_batch(sd_f, c, x_T, x_cond, x_other, 10, chunk=1)[0][-1]
+
+        tr, to = [], []
+        run_ref(); run_oracle()                                          # warm-up (oneDNN primitive caches)
+        for _ in range(int(os.environ.get("WDM_TIMING_ROUNDS", "3"))):
+            t0 = time.perf_counter(); a = run_ref(); tr.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); b = run_oracle(); to.append(time.perf_counter() - t0)
+        check("timing runs agree", b, a)
+        r, o = min(tr), min(to)
+        delta = (o - r) / r
+        rec_ = {"workload": "BASELINE.json configs[0]: 4 x 64x64 wavelet-domain crops, 10 DDIM steps, fp32, torch CPU, 8 threads",
+                "reference_s": [round(v, 3) for v in tr], "oracle_s": [round(v, 3) for v in to], "reference_best_s": round(r, 3), "oracle_best_s": round(o, 3),
+                "oracle_minus_reference_rel": round(delta, 4), "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(),
+                "reference_img_per_s_at_100_steps": round(4 / (r * 10), 5), "oracle_img_per_s_at_100_steps": round(4 / (o * 10), 5)}
+        print(" ", json.dumps(rec_))
+        assert abs(delta) <= 0.05, f"oracle wall time differs from the reference's by {100 * delta:+.1f} % (BASELINE.md §3.2 allows 5 %)"
+        with open(out("oracle_timing.json"), "w") as f:
+            json.dump(rec_, f, indent=1)
+
+    if args.only_eta:
+        golden_eta()
+        return
+    if args.only_timing:
+        golden_timing()
+        return
     if args.only_config:
         golden_config()
         return
@@ -315,6 +399,7 @@ def main():
     golden_train()
     golden_variants()
     golden_config()
+    golden_eta()
 
     # ------------------------------------------------------------------ integer tables
     print("[tables]")
@@ -554,6 +639,8 @@ def main():
         check("C0 sampler x0[-5]", ox0[-5], ref_x0)
         full["c0_xs_last"], full["c0_x0_m5"] = ref_xs.numpy(), ref_x0.numpy()
         np.savez_compressed(out("full.npz"), **full)
+    if not args.skip_full:
+        golden_timing()
     print("golden fixtures written to", HERE)
 
 

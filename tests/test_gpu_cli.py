@@ -51,6 +51,48 @@ def test_train_then_eval_from_yaml(tmp_path):
     assert out.count("=> loaded checkpoint") == 2 and not (tmp_path / "img2").exists()
 
 
+def test_default_compute_mode_is_f16_with_a_loud_fallback(monkeypatch):
+    """No mode named anywhere -> DenoisingDiffusion_Wavelet samples in f16 (the fastest mode inside north_star's 1e-3 on sampler outputs: bench.py `parity_mode`);
+    a checkpoint fp16 cannot hold -> bf16 with a RuntimeWarning, and the sampler runs; an EXPLICIT dtype='f16' on that checkpoint raises."""
+    import wavedm_amd
+    from wavedm_amd import _lib
+    from wavedm_amd import procedural as P
+    monkeypatch.delenv("WAVEDM_DTYPE", raising=False)
+    cfg = P.reduced_config()
+    cfg.device = torch.device("cuda", 0)
+    args = SimpleNamespace(resume="", sampling_timesteps=5, local_rank=0, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=16)
+    sd = P.procedural_state_dict(cfg)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x)
+    assert d.model.dtype_name == "f16" and d.model._dtype_code == _lib.WDM_F16
+    d.model.load_state_dict(sd, strict=True)
+    rainy, x_T = P.synthetic_batch(2, patch_px=64)
+    out, xs_last, _ = d.restore_batch(rainy.cuda(), x_T.cuda(), keep=-1)
+    assert d.model.dtype_name == "f16"
+    xc = O.dwt_fwd(2 * rainy - 1)
+    oxs, _ = O.ddim_batch(sd, cfg, x_T, xc, xc[:, 3:], 5)
+    assert float((xs_last.cpu() - oxs[-1]).abs().max() / oxs[-1].abs().max()) <= 2.5e-3       # (the reduced model's bound for f16, __graft_entry__.smoke)
+    # explicit choices are kept
+    cfg2 = P.reduced_config()
+    cfg2.device = cfg.device
+    cfg2.model.hip_dtype = "bf16"
+    assert wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg2, generator=lambda x: x).model.dtype_name == "bf16"
+    assert wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32x3").model.dtype_name == "f32x3"
+    # a weight outside the fp16 range: automatic -> bf16, loudly; explicit f16 -> error
+    bad = dict(sd)
+    k = "mid.block_1.conv1.weight"
+    bad[k] = sd[k].clone()
+    bad[k][0, 0, 0, 0] = 1.0e5
+    d2 = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x)
+    d2.model.load_state_dict(bad, strict=True)
+    with pytest.warns(RuntimeWarning, match="DOES NOT FIT THE DEFAULT f16 MODE"):
+        out2, _, _ = d2.restore_batch(rainy.cuda(), x_T.cuda(), keep=-1)
+    assert d2.model.dtype_name == "bf16" and bool(torch.isfinite(out2).all())
+    d3 = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f16")
+    d3.model.load_state_dict(bad, strict=True)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        d3.restore_batch(rainy.cuda(), x_T.cuda(), keep=-1)
+
+
 def test_bench_parity_mode_is_the_fastest_conformant_mode():
     """bench.py's contract for `parity_mode` (round 5): the FASTEST mode whose full-length deviation measured <= 1e-3 in that very run -- f16 on this build -- with the
     fp32-tensor mode and the exact mode beside it; a reduced call (8 crops, 10 DDIM steps) exercises the whole leg."""
@@ -65,9 +107,16 @@ def test_bench_parity_mode_is_the_fastest_conformant_mode():
     pm = line["parity_mode"]
     assert pm["dtype"] == "f16" and pm["rel_linf_vs_f32_full_length"] <= 1e-3 and pm["value"] > pm["f32x3"]["value"] > pm["exact_f32"]["value"]
     assert pm["f32x3"]["rel_linf_vs_f32_full_length"] <= 1e-4 and pm["roofline"]["peak"] == 2500.0
-    assert line["dtype"] == "bf16" and line["roofline"]["sustained"]["peak"] == 1845.0 and line["roofline"]["frac"] < line["roofline"]["sustained"]["frac"]
+    assert line["dtype"] == "bf16"
     # the board's own roofs, measured by the bench behind its timed passes (tools/abl_mfma_power, built by __graft_entry__.build()): the LDS-fed loop sits below the
-    # register-resident one, both below the nominal peak, and the kernel below both
-    tb = line["roofline"]["sustained"].get("this_board")
+    # register-resident one, both below the nominal peak, and the kernel below both.  With them on the line NO fraction is taken against the board-class constants
+    # (every fraction belongs to the timed box); the quoted PMC traffic figure says that it is quoted
+    sus = line["roofline"]["sustained"]
+    tb = sus.get("this_board")
     if os.path.isfile(os.path.join(repo, "tools", "abl_mfma_power")):
-        assert tb and 900.0 < tb["lds_fed"] < tb["register_resident"] < 2500.0 and 0.0 < tb["frac_of_lds_fed"] < 1.0, tb
+        assert tb and 900.0 < tb["lds_fed"] < tb["register_resident"] < 2500.0 and 0.0 < tb["frac_of_register_resident"] < tb["frac_of_lds_fed"] < 1.0, tb
+        assert "frac" not in sus and "peak" not in sus and sus["board_class"]["register_resident"] == 1845.0 and "frac" not in sus["board_class"]
+        assert line["roofline"]["frac"] < tb["frac_of_register_resident"]
+    else:
+        assert sus["peak"] == 1845.0 and line["roofline"]["frac"] < sus["frac"]
+    assert line["roofline"]["traffic_source"] in ("quoted", None) and (line["roofline"]["traffic"] is None or "QUOTED" in line["roofline"]["traffic_unit"])

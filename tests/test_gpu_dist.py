@@ -87,6 +87,77 @@ def test_bench_self_launches_two_ranks():
     assert rec["value"] > 0 and rec["scaling"] == "weak"
 
 
+def _bench_ranks(n, extra, timeout=1500):
+    import json
+    repo = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["WAVEDM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-extras"] + extra,
+                       env=env, capture_output=True, text=True, timeout=timeout, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_eight_rank_dress_rehearsal_configs3():
+    """The driver's 8-GPU scaling run, rehearsed on ONE device: `python bench.py --gpus 8` self-launches eight ranks (the reference's launch shape,
+    train_weather_script.py:3: eight processes, one per GPU), rank 0 packs the weights, broadcast + adopt on the other seven, 64 crops per rank = BASELINE configs[3]'s
+    global batch of 512, barriers and the max over ranks, the roofline leg on rank 0 while seven ranks wait, ragged-free all-gather after the clock.  gloo so that the
+    eight ranks can share this box's GPU; the collectives' call sites are the ones RCCL will run."""
+    rec = _bench_ranks(8, ["--ddim-steps", "5"])            # (the shortest run that has an x0_preds[-5])
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 512 and rec["config"]["outputs_finite"] and rec["scaling"] == "weak"
+    assert rec["rccl"]["rccl_ranks"] == 8 and rec["rccl"]["weight_broadcast_s"] is not None and rec["rccl"]["rank_elapsed_s_max"] >= rec["rccl"]["rank_elapsed_s_min"] > 0
+    assert rec["value"] > 0 and rec["roofline"]["launches"] > 0 and rec["cpu_baseline"] is None
+
+
+def test_bench_eight_rank_dress_rehearsal_configs4():
+    """configs[4] on eight ranks, both forms of SURVEY.md §8e: (i) replicas by image -- 8 whole 480x720 images per rank through DiffusiveRestoration.restore();
+    (ii) ONE image patch-sharded -- its 45 patches split 6/6/6/6/6/5/5/5, one all-reduce(sum) of the partial sums and counts per DDIM step."""
+    rec = _bench_ranks(8, ["--workload", "c4", "--ddim-steps", "5", "--batch", "2", "--no-roofline"])
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 16 and rec["config"]["outputs_finite"] and rec["rccl"]["rccl_ranks"] == 8
+    rec = _bench_ranks(8, ["--workload", "c4", "--ddim-steps", "5", "--patch-sharded"])
+    assert rec["rccl"]["patch_shards"] == [6, 6, 6, 6, 6, 5, 5, 5] and rec["rccl"]["allreduce_bytes_per_step"] == 2 * 3 * 120 * 180 * 4
+    assert rec["config"]["global_batch"] == 1 and rec["scaling"] == "strong" and rec["config"]["outputs_finite"] and rec["value"] > 0
+    assert "patch-sharded x8" in rec["config"]["parallelism"]
+
+
+def test_patch_sharded_restore_on_eight_ranks_matches_one_process(tmp_path):
+    """The 45-patch split on the REAL geometry (one 480x720 image -> 120x180 wavelet domain, 64x64 patches every 16) over eight ranks on one device: the restored
+    image equals the single-process restore() to the association of eight partial overlap sums (fp32; 1e-5 max-norm-relative), reduced-width UNet at resolution 64."""
+    import wavedm_amd
+    out = tmp_path / "ps8.pt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", WDM_TEST_BACKEND="gloo", WDM_TEST_MODE="patch8")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "dist_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    assert got["world"] == 8 and got["shards"] == [6, 6, 6, 6, 6, 5, 5, 5]
+    d, args, img = patch8_setup(torch.device("cuda", 0))
+    rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
+    torch.manual_seed(77)
+    outs, psnr = rest.restore([(img, ("one",), torch.zeros(1))], validation="raindrop", r=16)
+    assert rel_linf(got["out"], outs[0].cpu()) <= 1e-5
+    assert abs(got["psnr"] - psnr[0]) <= 1e-3
+
+
+def patch8_setup(dev):
+    """One 480x720 image and a 64-resolution UNet of reduced width (ch 32, levels (1, 2), attention at 32) -- shared by the eight ranks and the single process."""
+    import wavedm_amd
+    cfg = P.raindrop_wavelet_config(image_size=64, ch=32, ch_mult=(1, 2), attn_resolutions=(32,))
+    cfg.device = dev
+    args = SimpleNamespace(resume="", sampling_timesteps=6, local_rank=dev.index, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=16, images_per_call=1)
+    d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")
+    d.model.load_state_dict(P.procedural_state_dict(cfg), strict=True)
+    img = torch.rand(1, 6, 480, 720, generator=torch.Generator().manual_seed(91))
+    return d, args, img
+
+
 def test_bench_refuses_more_gpus_than_present():
     """Asking for more RCCL ranks than the node has devices answers with one JSON line (value null, error text) and a non-zero exit."""
     import json

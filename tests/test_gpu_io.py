@@ -79,6 +79,61 @@ def test_images_per_call_is_bit_identical_and_pngs_match(tmp_path):
             assert np.array_equal(gt_png, O.to_u8_hwc(items[k][0][:, 3:])[0].numpy())
 
 
+def test_restore_defaults_early_stop_and_auto_grouping_are_bit_identical(tmp_path):
+    """restore() as a caller of the reference gets it (no images_per_call / early_stop in args): early stop at x0_preds[-5] (restoration.py:108 reads nothing behind
+    it), as many same-sized images per sampler call as fill the UNet calls, groups pipelined two deep -- against the plain loop (every step, one image per call):
+    the same bits per image, the same PSNRs, the same console order."""
+    import wavedm_amd
+    d, args = _diffusion(8)
+    g = torch.Generator().manual_seed(33)
+    items = [(torch.rand(1, 6, 96, 112, generator=g), (f"im{k}",), torch.zeros(1)) for k in range(7)]       # 24x28 wavelet domain: 3 x 4 = 12 patches of 16
+    items.insert(4, (torch.rand(1, 6, 64, 80, generator=g), ("odd",), torch.zeros(1)))                        # a different size in the middle closes a group
+    args.max_batch = 32                                                                                     # UNet calls of at most 32 patches: 48 = 32 + 16 -> two calls of 24, ...
+    res = {}
+    for tag, kw in (("plain", dict(images_per_call=1, early_stop=False)), ("default", {}), ("early1", dict(images_per_call=1)), ("late_auto", dict(early_stop=False))):
+        a = SimpleNamespace(**vars(args))
+        for k, v in kw.items():
+            setattr(a, k, v)
+        a.image_folder = str(tmp_path / tag)
+        rest = wavedm_amd.DiffusiveRestoration(d, a, d.config, save_images=False)
+        if tag == "default":
+            assert rest.images_per_call_for(24, 28, 4) == 8 and rest.images_per_call_for(16, 20, 4) > 1          # several images per call, by default
+        torch.manual_seed(5)
+        o, psnr = rest.restore(items, validation="raindrop", r=4)
+        res[tag] = ([t.cpu() for t in o], list(psnr), list(rest.last_psnrs_y))
+    assert len(res["plain"][0]) == 8
+    for tag in ("default", "early1", "late_auto"):
+        for k in range(8):
+            assert torch.equal(res["plain"][0][k], res[tag][0][k]), (tag, k)
+        assert res[tag][1] == res["plain"][1] and res[tag][2] == res["plain"][2]
+    # the early stop really stops: sample_image hands back None behind x0_preds[-5]
+    x_cond = d.wavelet_dec.forward_affine(items[0][0][:, :3].to(dev()).contiguous())
+    torch.manual_seed(1)
+    xs, x0 = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False).diffusive_restoration(
+        x_cond, x_other=x_cond[:, 3:].contiguous(), r=4, last=False, use_other=True, stop_at=-5)
+    assert len(x0) == 8 and x0[-5] is not None and all(t is None for t in x0[-4:]) and all(t is None for t in xs[-4:])
+    with pytest.raises(ValueError):
+        d.sample_image(x_cond, torch.randn(1, 3, 24, 28, device=dev()), x_other=x_cond[:, 3:].contiguous(), last=True, patch_locs=[(0, 0)], patch_size=16,
+                       use_other=True, stop_at=-5)
+
+
+def test_restore_surfaces_loader_errors_and_short_schedules(tmp_path):
+    import wavedm_amd
+    d, args = _diffusion(6)
+    args.image_folder = str(tmp_path)
+
+    def bad_loader():
+        yield torch.rand(1, 6, 64, 80), ("ok",), torch.zeros(1)
+        raise OSError("truncated PNG")
+    rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
+    with pytest.raises(OSError, match="truncated PNG"):
+        rest.restore(bad_loader(), validation="raindrop", r=4)
+    d4, a4 = _diffusion(4)                                      # x0_preds[-5] of a 4-step run: the reference's IndexError (restoration.py:108)
+    a4.image_folder = str(tmp_path)
+    with pytest.raises(IndexError):
+        wavedm_amd.DiffusiveRestoration(d4, a4, d4.config, save_images=False).restore([(torch.rand(1, 6, 64, 80), ("x",), torch.zeros(1))], r=4)
+
+
 def test_loader_to_restore_pipeline(tmp_path):
     """datasets.RainDrop loaders -> DiffusiveRestoration.restore, two images per call, PSNR against the oracle's restore()."""
     import wavedm_amd

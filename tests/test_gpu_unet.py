@@ -545,3 +545,53 @@ def test_sampling_loop_replayed_from_a_hipgraph_gives_the_same_bits():
         for u, v in zip(a, b):
             assert torch.equal(u, v)
     sampling.graph_cache_clear()
+
+
+def test_eta_nonzero_matches_the_reference(golden, monkeypatch):
+    """eta != 0 in generalized_steps_overlapping (ddm_wavelet.py:500-502): c1 * randn_like(x) enters x_next.  The reference's run with eta = 0.5 (reduced model,
+    24x28 image, 12 stitched patches, 6 steps) is the fixture; its per-step draws are fed to the device sampler in place of torch.randn_like."""
+    from oracle import wavedm_oracle as O
+    from wavedm_amd import procedural as P
+    e = golden("eta.npz")
+    S, eta = int(e["S"]), float(e["eta"])
+    seq = range(0, 1000, 1000 // S)                               # (sample_image's sequence for sampling_timesteps = 6: SEVEN steps, 0, 166, ..., 996)
+    nst = len(seq)
+    assert nst == len(e["noises"])
+    d, args = make_diffusion(P.reduced_config(), "f32", S)
+    xc, xT = torch.from_numpy(e["x_cond"]).cuda(), torch.from_numpy(e["x_T"]).cuda()
+    draws = [torch.from_numpy(z).cuda() for z in e["noises"]]
+    real = torch.randn_like
+    calls = []
+
+    def fake(t, *a, **k):
+        calls.append(tuple(t.shape))
+        return draws[len(calls) - 1].clone()
+    monkeypatch.setattr(torch, "randn_like", fake)
+    corners = O.grid_corners(24, 28, 16, 4)
+    xs, x0 = d.generalized_steps_overlapping(xT, xc, seq, d.model, d.betas, eta=eta, corners=corners, p_size=16,
+                                             x_other=xc[:, 3:].contiguous(), use_other=True)
+    monkeypatch.setattr(torch, "randn_like", real)
+    assert calls == [(1, 3, 24, 28)] * nst                          # one draw of x's shape per step, like the reference
+    for name, got in (("xs_last", xs[-1]), ("x0_last", x0[-1]), ("xs_2", xs[2])):
+        err = rel_linf(got.cpu(), e[name])
+        print(f"eta = {eta} {name}: rel_linf vs the reference {err:.3e}")
+        assert err <= 1e-3
+    # eta = 0 through the same entry stays the deterministic sampler (no draw)
+    calls.clear()
+    xs0, _ = d.generalized_steps_overlapping(xT, xc, seq, d.model, d.betas, eta=0., corners=corners, p_size=16,
+                                             x_other=xc[:, 3:].contiguous(), use_other=True)
+    assert not calls and not torch.equal(xs0[2], xs[2])
+    # and against the oracle with draws of the device generator (batched crops: corners=None path of ddim_sample)
+    from wavedm_amd import sampling
+    torch.manual_seed(7)
+    zs = [torch.randn(2, 3, 16, 16, device="cuda") for _ in range(nst)]
+    it = iter(zs)
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: next(it).clone())
+    xc2, xT2 = seeded((2, 48, 16, 16), 820).cuda(), seeded((2, 3, 16, 16), 821).cuda()
+    xs_b, x0_b = sampling.ddim_sample(d.model, xT2, xc2, xc2[:, 3:].contiguous(), list(seq), d.betas, eta=0.3)
+    monkeypatch.setattr(torch, "randn_like", real)
+    sd = P.procedural_state_dict(P.reduced_config())
+    for i in range(2):
+        oxs, _ = O.ddim_overlapping(sd, P.reduced_config(), xT2[i:i + 1].cpu(), xc2[i:i + 1].cpu(), xc2[i:i + 1, 3:].cpu(), [(0, 0)], 16, S, eta=0.3,
+                                    noises=[z[i:i + 1].cpu() for z in zs])
+        assert rel_linf(xs_b[-1][i:i + 1].cpu(), oxs[-1]) <= 1e-3 and rel_linf(xs_b[3][i:i + 1].cpu(), oxs[3]) <= 1e-3

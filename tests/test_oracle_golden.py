@@ -124,6 +124,19 @@ def test_stitched_restore(golden):
     assert rel_linf(out, s["out"]) <= 1e-5
 
 
+def test_eta_nonzero_sampler(golden):
+    """ddm_wavelet.py:500-502 with eta = 0.5: the oracle fed the reference's own per-step draws reproduces its trajectory."""
+    e = golden("eta.npz")
+    cfg = P.reduced_config()
+    sd = P.procedural_state_dict(cfg)
+    xc, xT = torch.from_numpy(e["x_cond"]), torch.from_numpy(e["x_T"])
+    xs, x0 = O.ddim_overlapping(sd, cfg, xT, xc, xc[:, 3:], O.grid_corners(24, 28, 16, 4), 16, int(e["S"]), eta=float(e["eta"]),
+                                noises=[torch.from_numpy(z) for z in e["noises"]])
+    assert rel_linf(xs[-1], e["xs_last"]) <= 1e-5 and rel_linf(x0[-1], e["x0_last"]) <= 1e-5 and rel_linf(xs[2], e["xs_2"]) <= 1e-5
+    xs0, _ = O.ddim_overlapping(sd, cfg, xT, xc, xc[:, 3:], O.grid_corners(24, 28, 16, 4), 16, int(e["S"]))
+    assert rel_linf(xs0[2], e["xs_2"]) > 1e-3                      # the draws matter
+
+
 @pytest.mark.parametrize("kind", P.VARIANTS)
 def test_optional_unet_branches(golden, kind):
     """use_other_channels False, data.use_window, data.wavelet_in_unet (unet.py:212, :347-350, :387-391)."""

@@ -60,6 +60,46 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        # the 45-patch list of one 480x720 image over 8 ranks: 6/6/6/6/6/5/5/5, gathered back in patch order
+        for n in (45, 512, 13, 5):                                # ragged, even (configs[3]'s 512 images), and fewer items than ranks (empty shards)
+            lo, hi = parallel.shard_range(n, rank, world)
+            local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 2, 3).contiguous() * 2 + 1
+            got = parallel.all_gather_shards(local, n)
+            want = (torch.arange(n, dtype=torch.float32).view(-1, 1, 1).expand(-1, 2, 3) * 2 + 1)
+            ok = ok and got.shape == (n, 2, 3) and torch.equal(got, want)
+        sizes = [parallel.shard_range(45, r, world)[1] - parallel.shard_range(45, r, world)[0] for r in range(world)]
+        ok = ok and sizes == [6, 6, 6, 6, 6, 5, 5, 5]
+        u = FakeUNet(rank)
+        buf = parallel.broadcast_weights(u, src=0)
+        ok = ok and torch.equal(buf, torch.arange(1000, dtype=torch.uint8)) and (u.adopted == (rank != 0))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_ragged_all_gather():
+    """World size 8 (the node the reference is launched on, train_weather_script.py:3): ragged, even and partly empty shards through all_gather_shards."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(8)]
+
+
 def test_two_rank_gloo_sharded_restore_and_broadcast():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -65,6 +65,7 @@ def lib():
         "wdm_dwt_inv": (i, [vp, vp, vp, i, i, i, vp]),
         "wdm_pack_channels": (i, [vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]),
         "wdm_ddim_update": (i, [vp, vp, vp, i, i, vp, i, i, i, f, f, f, f, vp, vp, vp]),
+        "wdm_ddim_update_eta": (i, [vp, vp, vp, i, i, vp, i, i, i, f, f, f, f, f, vp, vp, vp, vp]),
         "wdm_patch_accumulate": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
         "wdm_ddim_from_sums": (i, [vp, vp, vp, i, i, i, f, f, f, f, vp, vp, vp]),
         "wdm_nchw_to_nhwc": (i, [vp, vp, vp, i, i, i, i, i, vp]),
@@ -132,7 +133,7 @@ def lib():
 
 
 EXPORTED = ["wdm_abi_version", "wdm_last_error", "wdm_create", "wdm_destroy", "wdm_dwt_fwd", "wdm_dwt_inv",
-            "wdm_pack_channels", "wdm_ddim_update", "wdm_patch_accumulate", "wdm_ddim_from_sums", "wdm_nchw_to_nhwc", "wdm_nhwc_to_nchw", "wdm_unet_create",
+            "wdm_pack_channels", "wdm_ddim_update", "wdm_ddim_update_eta", "wdm_patch_accumulate", "wdm_ddim_from_sums", "wdm_nchw_to_nhwc", "wdm_nhwc_to_nchw", "wdm_unet_create",
             "wdm_unet_destroy", "wdm_unet_num_params", "wdm_unet_param_info", "wdm_unet_packed_bytes",
             "wdm_unet_set_packed", "wdm_unet_load_param", "wdm_unet_mark_loaded", "wdm_unet_workspace_bytes",
             "wdm_unet_forward", "wdm_unet_temb_rows", "wdm_unet_temb_table", "wdm_unet_forward_temb", "wdm_resblock_forward", "wdm_attn_forward", "wdm_conv_forward", "wdm_temb_forward",

@@ -77,6 +77,11 @@ int wdm_ddim_update(wdm_handle* h, const float* eps, const int32_t* patches, int
     if (!h || !eps || !x_t || !x0_out || !x_next_out) WDM_FAIL(WDM_EINVAL, "wdm_ddim_update: null argument");
     return k_ddim_update(eps, patches, n, p, x_t, nimg, H, W, sqrt_1m_at, sqrt_at, sqrt_at_next, c2, x0_out, x_next_out, (hipStream_t)stream);
 }
+int wdm_ddim_update_eta(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W, float sqrt_1m_at,
+                        float sqrt_at, float sqrt_at_next, float c1, float c2, const float* noise, float* x0_out, float* x_next_out, void* stream) {
+    if (!h || !eps || !x_t || !x0_out || !x_next_out || !noise) WDM_FAIL(WDM_EINVAL, "wdm_ddim_update_eta: null argument");
+    return k_ddim_update(eps, patches, n, p, x_t, nimg, H, W, sqrt_1m_at, sqrt_at, sqrt_at_next, c2, x0_out, x_next_out, (hipStream_t)stream, noise, c1);
+}
 int wdm_patch_accumulate(wdm_handle* h, const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W, float* acc_cnt, void* stream) {
     if (!h || !acc_cnt || (n > 0 && (!eps || !patches))) WDM_FAIL(WDM_EINVAL, "wdm_patch_accumulate: null argument");
     if (n == 0) {      // a rank that owns no patch of this step contributes zeros

@@ -148,7 +148,7 @@ int k_dwt_inv(const float* y, float* x, int B, int h, int w, hipStream_t s, cons
 int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patches, int n, int p, void* x96,
                     int c_total, int c_off, int dtype, hipStream_t s);
 int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W,
-                  float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s);
+                  float s1m, float sa, float san, float c2, float* x0, float* xn, hipStream_t s, const float* noise = nullptr, float c1 = 0.f);
 int k_patch_accumulate(const float* eps, const int32_t* patches, int n, int p, int nimg, int H, int W, float* acc_cnt, hipStream_t s);
 int k_ddim_from_sums(const float* acc_cnt, const float* x_t, int nimg, int H, int W, float s1m, float sa, float san, float c2, float* x0,
                      float* xn, hipStream_t s);

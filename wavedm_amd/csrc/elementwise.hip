@@ -175,7 +175,7 @@ int k_pack_channels(const float* src, int nch, int H, int W, const int32_t* patc
 // =================================================================================================
 __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ eps, const int32_t* __restrict__ patches, int n, int p,
                                                           const float* __restrict__ x_t, int nimg, int H, int W, float s1m, float sa, float san, float c2,
-                                                          float* __restrict__ x0o, float* __restrict__ xno) {
+                                                          float* __restrict__ x0o, float* __restrict__ xno, const float* __restrict__ noise, float c1) {
     const long long total = (long long)nimg * 3 * H * W;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
         const int xx = (int)(id % W);
@@ -199,17 +199,18 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
         const float xt = x_t[id];
         const float x0 = (xt - et * s1m) / sa;
         x0o[id] = x0;
-        xno[id] = san * x0 + c2 * et;
+        // eta != 0 (ddm_wavelet.py:500-502): at_next.sqrt() * x0_t + c1 * randn_like(x) + c2 * et, summed left to right like the reference's expression
+        xno[id] = noise ? san * x0 + c1 * noise[id] + c2 * et : san * x0 + c2 * et;
     }
 }
 
 int k_ddim_update(const float* eps, const int32_t* patches, int n, int p, const float* x_t, int nimg, int H, int W, float s1m, float sa, float san,
-                  float c2, float* x0, float* xn, hipStream_t s) {
+                  float c2, float* x0, float* xn, hipStream_t s, const float* noise, float c1) {
     if (n <= 0 || nimg <= 0) WDM_FAIL(WDM_EINVAL, "ddim_update: bad arguments");
     if (patches == nullptr && (p != H || p != W || n != nimg)) WDM_FAIL(WDM_EINVAL, "ddim_update: identity patch list needs n == nimg, p == H == W");
     const long long total = (long long)nimg * 3 * H * W;
     const int g = nblocks(total, 256) > 16384 ? 16384 : nblocks(total, 256);
-    hipLaunchKernelGGL(ddim_update_kernel, dim3(g), dim3(256), 0, s, eps, patches, n, p, x_t, nimg, H, W, s1m, sa, san, c2, x0, xn);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(g), dim3(256), 0, s, eps, patches, n, p, x_t, nimg, H, W, s1m, sa, san, c2, x0, xn, noise, c1);
     WDM_HIP(hipGetLastError());
     return WDM_OK;
 }

@@ -175,7 +175,7 @@ struct wdm_unet {
     AttnW aw(const AttnD& d) const { AttnW a; a.c = d.c; a.n = nw(d.n); a.qk = cw(d.qk); a.v = cw(d.v); a.proj = cw(d.proj); if (d.fold >= 0) { a.qf = cw(d.qf); a.pf = cw(d.pf); } return a; }
 
     int refold(const ParamSlot& p, const float* dev_src, hipStream_t s);
-    int check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s);
+    int check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s, float limit = 65504.0f);
     int forward(Ctx& c, const void* x96, const float* t, int n_t, float* eps_out, const float* temb_pre = nullptr);
     int temb_table(Ctx& c, const float* t, int n_t, float* temb_all);
 };
@@ -253,14 +253,14 @@ int wdm_unet::build() {
 
 // fp16 operands: a weight outside +-65504 (or not finite) would become inf in the packed matrix -- refuse it, loudly.  The one place the weight loader waits for the
 // stream (set-up path; the sampling path never does)
-int wdm_unet::check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s) {
+int wdm_unet::check_f16_range(const float* dev, int64_t n, const char* what, hipStream_t s, float limit) {
     int* flag = (int*)(packed + range_flag_off);
     int host_flag = 0;
     WDM_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-    WDM_TRY(k_flag_out_of_range(dev, n, 65504.0f, flag, s));
+    WDM_TRY(k_flag_out_of_range(dev, n, limit, flag, s));
     WDM_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     WDM_HIP(hipStreamSynchronize(s));
-    if (host_flag) WDM_FAIL(WDM_EINVAL, "parameter '%s': a value lies outside the fp16 range (|w| <= 65504, finite) -- use WDM_BF16 or WDM_F32X3 for this checkpoint", what);
+    if (host_flag) WDM_FAIL(WDM_EINVAL, "parameter '%s': a value lies outside the fp16 range (|w| <= %.0f, finite) -- use WDM_BF16 or WDM_F32X3 for this checkpoint", what, (double)limit);
     return WDM_OK;
 }
 
@@ -508,7 +508,8 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
     hipStream_t s = (hipStream_t)stream;
     if (p.kind == PK_CONV) {
         const int cout = (int)p.shape[0], cin = (int)p.shape[1], k = (int)p.shape[2];
-        if (u->cfg.dtype == WDM_F16) WDM_TRY(u->check_f16_range(dev_src, numel, name, s));
+        // (an Upsample conv is ALSO packed as pre-summed sub-pixel taps, up to four weights each, k_pack_up4: a quarter of the range keeps every sum inside it -- ADVICE r5)
+        if (u->cfg.dtype == WDM_F16) WDM_TRY(u->check_f16_range(dev_src, numel, name, s, p.up4_off ? 65504.0f / 4 : 65504.0f));
         WDM_TRY(k_pack_conv(dev_src, cout, cin, k, u->packed + p.off, p.rows_total, p.row_off, p.zero_tail ? 1 : 0, u->cfg.dtype, s, p.cin_dst));
         if (p.sm_off) WDM_TRY(k_pack_conv_sm(dev_src, cout, cin, u->packed + p.sm_off, p.rows_total, s, u->cfg.dtype));
         if (p.up4_off) WDM_TRY(k_pack_up4(dev_src, cout, cin, u->packed + p.up4_off, p.rows_total, s, u->cfg.dtype));
@@ -516,7 +517,14 @@ int wdm_unet_load_param(wdm_unet* u, const char* name, const float* dev_src, int
         WDM_TRY(k_copy_f32(dev_src, (float*)(u->packed + p.off) + p.row_off, numel, s));
     }
     p.loaded = true;
-    if (p.fold >= 0) WDM_TRY(u->refold(p, dev_src, s));
+    if (p.fold >= 0) {
+        const int rc = u->refold(p, dev_src, s);
+        if (rc != WDM_OK) {                   // the folded operand was not rebuilt: this tensor does not count as loaded, and nothing runs until it is
+            p.loaded = false;
+            u->all_loaded = false;
+            return rc;
+        }
+    }
     bool all = true;
     for (auto& q : u->params) all = all && q.loaded;
     u->all_loaded = all;

@@ -53,7 +53,13 @@ class DenoisingDiffusion_Wavelet(object):
             from .unet_global import DiffusionUNet_Global
             self.model = DiffusionUNet_Global(config, dtype=dtype).to(self.device)
         else:
-            self.model = DiffusionUNet(config, dtype=dtype).to(self.device)
+            # No mode named anywhere (argument, config.model.hip_dtype, WAVEDM_DTYPE): the sampler runs in f16 -- the bf16 kernels on fp16 operands, the throughput
+            # mode's speed at <= 1e-3 of the fp32 result ON SAMPLER OUTPUTS (xs, x0_preds, restored images; one UNet forward alone sits at 1.15e-3 ... 1.34e-3 of
+            # max|eps|: DESIGN 3.9) -- unless the checkpoint holds a weight fp16 cannot: then bf16, with a RuntimeWarning (DiffusionUNet.pack_weights)
+            auto = dtype is None and not getattr(config.model, "hip_dtype", None) and not os.environ.get("WAVEDM_DTYPE")
+            self.model = DiffusionUNet(config, dtype="f16" if auto else dtype).to(self.device)
+            if auto:
+                self.model._dtype_fallback = "bf16"
         self.start_epoch, self.step = 0, 0
         self.ema_shadow = None
         self.optimizer_state = None
@@ -205,8 +211,12 @@ class DenoisingDiffusion_Wavelet(object):
                                "sample_image(..., total=<whole image>, use_global=True)")
 
     def sample_image(self, x_cond, x, x_other=None, last=True, patch_locs=None, patch_size=None, total=None,
-                     use_global=False, use_other=False):
-        """ddm_wavelet.py:295-309."""
+                     use_global=False, use_other=False, stop_at=None):
+        """ddm_wavelet.py:295-309.  `stop_at` (not in the reference; default None = every step, like the reference): a negative index k -- the caller reads
+        nothing after x0_preds[k], so the steps behind it are skipped and the lists padded with None (sampling.ddim_sample).  DiffusiveRestoration.restore,
+        which consumes x0_preds[-5] only (restoration.py:108), passes -5."""
+        if last and stop_at is not None:
+            raise ValueError("sample_image: last=True returns xs[-1], which an early stop does not compute")
         skip = self.config.diffusion.num_diffusion_timesteps // self.args.sampling_timesteps
         seq = range(0, self.config.diffusion.num_diffusion_timesteps, skip)
         if patch_locs is None:
@@ -214,22 +224,23 @@ class DenoisingDiffusion_Wavelet(object):
             # model's resolution and the UNet sees [x_cond | x_t] (its conv_in must be built for that width: model.use_other_channels False)
             # (generalized_steps starts from x as given whatever data.begin_from_noise says: there is no q-sample of x_cond on this path)
             self._require_plain_unet("sample_image(patch_locs=None)")
-            xs = sampling.ddim_sample(self.model, x, x_cond, None, list(seq), self.betas, corners=None, max_batch=getattr(self.args, "max_batch", 64))
+            xs = sampling.ddim_sample(self.model, x, x_cond, None, list(seq), self.betas, corners=None, max_batch=getattr(self.args, "max_batch", 64),
+                                      stop_at=stop_at)
             return xs[0][-1] if last else xs
         xs = self.generalized_steps_overlapping(x, x_cond, seq, self.model, self.betas, eta=0., corners=patch_locs,
                                                 p_size=patch_size, total=total, use_global=use_global,
-                                                x_other=x_other, use_other=use_other)
+                                                x_other=x_other, use_other=use_other, stop_at=stop_at)
         if last:
             xs = xs[0][-1]
         return xs
 
     def generalized_steps_overlapping(self, x, x_cond, seq, model, b, eta=0., corners=None, p_size=None,
-                                      manual_batching=True, total=None, x_other=None, use_global=False, use_other=False):
-        """ddm_wavelet.py:437-506 on the device."""
-        if eta != 0.:
-            raise NotImplementedError("only eta = 0 (DDIM) is used by the reference (ddm_wavelet.py:303)")
+                                      manual_batching=True, total=None, x_other=None, use_global=False, use_other=False, stop_at=None):
+        """ddm_wavelet.py:437-506 on the device (eta != 0 included: :500-502, one randn_like(x) per step from the device generator)."""
         if use_global:
-            return self._ddim_overlapping_global(x, x_cond, list(seq), model, b, corners, p_size, total)
+            if stop_at is not None:
+                raise NotImplementedError("stop_at is not built for the use_global branch")
+            return self._ddim_overlapping_global(x, x_cond, list(seq), model, b, corners, p_size, total, eta=eta)
         self._require_plain_unet("generalized_steps_overlapping(use_global=False)")
         if not use_other:
             x_other = None                                                      # ddm_wavelet.py:471-473: the UNet sees [x_cond | x_t] only
@@ -241,13 +252,15 @@ class DenoisingDiffusion_Wavelet(object):
             import torch.distributed as dist
             dist.broadcast(x, src=0, group=None if grp is True else grp)
         xs, x0_preds = sampling.ddim_sample(model, x, x_cond, x_other, list(seq), b, corners=corners, p_size=p_size,
-                                            max_batch=getattr(self.args, "max_batch", 64), patch_group=grp)
+                                            max_batch=getattr(self.args, "max_batch", None) or sampling.DEFAULT_MAX_BATCH, patch_group=grp, eta=eta, stop_at=stop_at)
         if self.verbose:
             for i_t, x0, xn in zip(reversed(list(seq)), x0_preds, xs[1:]):
+                if x0 is None:
+                    break
                 print(f"t:{i_t} x0 pred:{x0.mean().item()} x next:{xn.mean().item()}")
         return xs, x0_preds
 
-    def _ddim_overlapping_global(self, x, x_cond, seq, model, b, corners, p_size, total):
+    def _ddim_overlapping_global(self, x, x_cond, seq, model, b, corners, p_size, total, eta=0.):
         """The `use_global` branch of generalized_steps_overlapping (ddm_wavelet.py:479-483): every patch is [x_cond crop | x_t crop] and the
         model also sees the whole image `total`, repeated for each patch.  Crops and concatenation are tensor plumbing; the UNet and the
         scatter-mean + DDIM update are library kernels (`wdm_ddim_update`, the one the main sampler uses)."""
@@ -279,9 +292,16 @@ class DenoisingDiffusion_Wavelet(object):
                 t = torch.tensor([float(i_t)], device=self.device)
                 eps = torch.cat([model(inp[i:i + 8], t, tot_p[i:i + 8]) for i in range(0, len(tri), 8)], dim=0).contiguous()      # manual_batching_size 8
                 x0, xn = torch.empty_like(xt), torch.empty_like(xt)
-                _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), _lib.ptr(patches), len(tri), p, _lib.ptr(xt), nimg, H, W, float((1 - at).sqrt()),
-                                             float(at.sqrt()), float(at_next.sqrt()), float((1 - at_next).sqrt()), _lib.ptr(x0), _lib.ptr(xn),
-                                             _lib.stream_ptr()))
+                if eta != 0.:                                                       # ddm_wavelet.py:500-502
+                    c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+                    noise = torch.randn_like(xt)
+                    _lib.check(L.wdm_ddim_update_eta(h, _lib.ptr(eps), _lib.ptr(patches), len(tri), p, _lib.ptr(xt), nimg, H, W, float((1 - at).sqrt()),
+                                                     float(at.sqrt()), float(at_next.sqrt()), float(c1), float(((1 - at_next) - c1 ** 2).sqrt()),
+                                                     _lib.ptr(noise), _lib.ptr(x0), _lib.ptr(xn), _lib.stream_ptr()))
+                else:
+                    _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), _lib.ptr(patches), len(tri), p, _lib.ptr(xt), nimg, H, W, float((1 - at).sqrt()),
+                                                 float(at.sqrt()), float(at_next.sqrt()), float((1 - at_next).sqrt()), _lib.ptr(x0), _lib.ptr(xn),
+                                                 _lib.stream_ptr()))
                 x0_preds.append(x0)
                 xs.append(xn)
                 xt = xn

@@ -35,10 +35,45 @@ def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_time
     return betas
 
 
+DEFAULT_MAX_BATCH = 384      # patches per UNet call of the stitched sampler when args.max_batch is not set (workspace ~ 40 MB per patch: 15 GB of the 288)
+
+_ABAR = {}          # id(betas tensor) -> (weak reference to it, its version counter, (abar table on the host, the betas' bytes))
+_DEVCONST = {}      # small read-only device tensors the launches read through raw pointers (patch lists, timestep rows)
+
+
+def _betas_entry(betas: torch.Tensor):
+    """The host-side view of a betas tensor, read back ONCE per tensor object (and per in-place update of it): `betas.cpu()` is a blocking copy on the current
+    stream, i.e. a wait for everything queued before it -- restore() keeps the next group of images queued behind the running one (restoration.py), so the
+    sampler must not synchronise on entry.  Keyed by object identity, checked through a weak reference (an id can be reused after its tensor is gone)."""
+    import weakref
+    ent = _ABAR.get(id(betas))
+    if ent is not None and ent[0]() is betas and ent[1] == betas._version:
+        return ent[2]
+    host = betas.detach().float().cpu()
+    b = torch.cat([torch.zeros(1, dtype=torch.float32), host], dim=0)
+    val = ((1 - b).cumprod(dim=0), host.numpy().tobytes())
+    for k in [k for k, e in _ABAR.items() if e[0]() is None]:
+        del _ABAR[k]
+    _ABAR[id(betas)] = (weakref.ref(betas), betas._version, val)
+    return val
+
+
 def alpha_bar_table(betas: torch.Tensor) -> torch.Tensor:
     """fp32 table T[t+1] = abar(t), T[0] = abar(-1) = 1 -- the cumprod of utils/sampling.py:11-12, on the CPU."""
-    b = torch.cat([torch.zeros(1, dtype=torch.float32), betas.detach().float().cpu()], dim=0)
-    return (1 - b).cumprod(dim=0)
+    return _betas_entry(betas)[0]
+
+
+def _device_const(dev, kind, values, dtype):
+    """A small constant on the device, uploaded once per distinct content: a pageable H2D copy waits for the stream (see _betas_entry), and the sampler is called
+    with the same patch list / timestep sequence for every group of same-sized images.  The tensors are never written."""
+    key = (str(dev), kind, values)
+    t = _DEVCONST.get(key)
+    if t is None:
+        t = torch.tensor(list(values), dtype=dtype).to(dev)
+        if len(_DEVCONST) >= 64:
+            _DEVCONST.pop(next(iter(_DEVCONST)))
+        _DEVCONST[key] = t
+    return t
 
 
 def compute_alpha(beta, t):
@@ -130,8 +165,8 @@ def graph_cache_clear():
 
 
 def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None, max_batch=64, keep="all", stop_at=None,
-                patch_group=None, streams=None):
-    """eta=0 DDIM over `seq` (ascending list of timesteps) for NIMG images.
+                patch_group=None, streams=None, eta=0.0):
+    """DDIM over `seq` (ascending list of timesteps) for NIMG images; eta = 0 (what every caller in the reference passes) is the deterministic sampler.
 
     x (NIMG,3,H,W) start noise, x_cond (NIMG,48,H,W), x_other (NIMG,45,H,W): fp32 on the GPU.
     corners: None -> every image is one p x p patch at (0,0) (p == H == W; the batched 64x64 case),
@@ -149,6 +184,9 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
           not depend on the batch an image sits in: the same bits as one stream (tests/test_gpu_unet.py).  Measured: +-2 % when the chunks' streams share a
           hardware queue, -35 % when they do not (_chunk_streams: kernels that take a whole CU each do not gain from running side by side).  Patch lists (overlap
           sums couple an image's patches every step) and per-launch profiling always run on one stream.
+    eta: the stochastic term of ddm_wavelet.py:500-502: c1 = eta*sqrt((1 - at/at_next)(1 - at_next)/(1 - at)), c2 = sqrt((1 - at_next) - c1^2), and
+          x_next = sqrt(at_next)*x0 + c1*randn_like(x) + c2*et -- one draw of x's shape per step from torch's device generator, like the reference.
+          Stochastic runs launch directly (no captured graph), on one stream, and not patch-sharded (every rank would need the same draw).
     patch_group: a torch.distributed process group (or True for the default group) = patch-sharded latency mode
           (SURVEY.md §8e-ii): the patch list is split contiguously over the ranks, each rank runs the UNet on its patches,
           and ONE all-reduce(sum) per step (RCCL) combines partial sums and overlap counts before the DDIM update, which every
@@ -161,6 +199,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         x_other = _lib.require_cuda_f32(x_other, "x_other")
     dev = x.device
     L, h = _lib.lib(), _lib.handle(dev.index or 0)
+    if hasattr(unet, "pack_weights"):
+        unet.pack_weights()                   # before the compute dtype is read: the automatic f16 mode may fall back while it packs (DiffusionUNet.pack_weights)
     nimg, pc, H, W = x.shape
     ncond, nother = x_cond.shape[1], (x_other.shape[1] if x_other is not None else 0)      # x_other None: model.use_other_channels False
     cin = unet.in_channels
@@ -189,7 +229,7 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                 lo, hi = shard_range(len(tri), dist.get_rank(grp), dist.get_world_size(grp))
                 tri = tri[lo:hi]
             n = len(tri)
-            patches = torch.tensor(tri if tri else [(0, 0, 0)], dtype=torch.int32).to(dev)
+            patches = _device_const(dev, "patches", tuple(tri) if tri else ((0, 0, 0),), torch.int32)
             pptr = _lib.ptr(patches)
         assert p == unet.resolution, "patch size must equal config.data.image_size (unet.py:351)"
         sharded = corners is not None and patch_group is not None
@@ -198,12 +238,19 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
         seq = list(seq)
         seq_next = [-1] + seq[:-1]
         abar = alpha_bar_table(betas)
-        t_dev = torch.tensor([float(v) for v in reversed(seq)], dtype=torch.float32).to(dev)
+        t_dev = _device_const(dev, "timesteps", tuple(float(v) for v in reversed(seq)), torch.float32)
         n_run = len(seq) if stop_at is None else len(seq) + int(stop_at) + 1
         assert 1 <= n_run <= len(seq), f"stop_at={stop_at} out of range for {len(seq)} steps"
         keep_set = None if keep == "all" else frozenset(int(v) for v in keep)
+        eta = float(eta)
+        if eta != 0.0 and sharded:
+            raise NotImplementedError("ddim_sample: eta != 0 with patch_group (every rank would have to draw the same noise)")
         ns = int(os.environ.get("WAVEDM_STREAMS", "1")) if streams is None else int(streams)
-        multi = corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on()
+        multi = corners is None and not sharded and ns > 1 and n >= 2 * ns and not _lib.prof_on() and eta == 0.0
+        # UNet calls per step: ceil(n / max_batch) calls of (nearly) EQUAL size -- 360 patches under a cap of 128 run as 3 x 120, not 128 + 128 + 104
+        # (per-image results do not depend on the batch an image sits in, tests/test_gpu_unet.py)
+        n_calls = max(1, -(-n // max_batch))
+        call_b = -(-n // n_calls) if os.environ.get("WAVEDM_EVEN_CALLS", "1") != "0" else max_batch
 
         def run_loop(x, x_cond, x_other, n_steps, use_chunks):
             """The sampling loop proper: every launch goes to the CURRENT stream (or the chunks' streams) -- also the body a hipGraph is captured from."""
@@ -216,7 +263,7 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
             eps = torch.empty(max(n, 1), pc, p, p, device=dev, dtype=torch.float32)
             acc_cnt = torch.empty(2 * x.numel(), device=dev, dtype=torch.float32) if sharded else None
             # the timestep-dependent part of the UNet (embedding MLP, every temb_proj) for the WHOLE sequence at once: four launches per run instead of per step
-            temb = unet.temb_table(t_dev, B=min(max(n, 1), max_batch)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
+            temb = unet.temb_table(t_dev, B=min(max(n, 1), call_b)) if os.environ.get("WAVEDM_TEMB_TABLE", "1") != "0" else None
             S = len(seq)
             xs, x0_preds = [x], []
             xt = x
@@ -244,6 +291,11 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                     at, at_next = abar[i_t + 1], abar[j_t + 1]                       # fp32 scalars, as compute_alpha returns
                     s1m, sa = float((1 - at).sqrt()), float(at.sqrt())
                     san, c2 = float(at_next.sqrt()), float((1 - at_next).sqrt())      # c1 = 0 (eta = 0)
+                    noise, c1 = None, 0.0
+                    if eta != 0.0:                                                    # ddm_wavelet.py:500-501, in fp32 tensors like the reference
+                        c1t = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+                        c1, c2 = float(c1t), float(((1 - at_next) - c1t ** 2).sqrt())
+                        noise = torch.randn_like(x)
                     x0 = torch.empty_like(x)
                     xn = torch.empty_like(x)
                     if chunks is not None:
@@ -260,19 +312,22 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                     else:
                         if n:
                             _lib.check(L.wdm_pack_channels(h, _lib.ptr(xt), pc, H, W, pptr, n, p, _lib.ptr(x96), cin, ncond, unet._dtype_code, st))
-                        for i in range(0, n, max_batch):
-                            unet.forward_nhwc(x96[i:i + max_batch], t_dev[k:k + 1], eps[i:i + max_batch], temb_row=None if temb is None else temb[k])
+                        for i in range(0, n, call_b):
+                            unet.forward_nhwc(x96[i:i + call_b], t_dev[k:k + 1], eps[i:i + call_b], temb_row=None if temb is None else temb[k])
                         if sharded:
                             _lib.check(L.wdm_patch_accumulate(h, _lib.ptr(eps), pptr, n, p, nimg, H, W, _lib.ptr(acc_cnt), st))
                             dist.all_reduce(acc_cnt, op=dist.ReduceOp.SUM, group=grp)
                             _lib.check(L.wdm_ddim_from_sums(h, _lib.ptr(acc_cnt), _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2, _lib.ptr(x0), _lib.ptr(xn), st))
+                        elif noise is not None:
+                            _lib.check(L.wdm_ddim_update_eta(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c1, c2, _lib.ptr(noise),
+                                                             _lib.ptr(x0), _lib.ptr(xn), st))
                         else:
                             _lib.check(L.wdm_ddim_update(h, _lib.ptr(eps), pptr, n, p, _lib.ptr(xt), nimg, H, W, s1m, sa, san, c2,
                                                          _lib.ptr(x0), _lib.ptr(xn), st))
                     # lists as the reference returns them; with `keep` given, what nobody asked for is dropped at once (inside a captured graph its memory is reused)
                     x0_preds.append(x0 if keep_set is None or (k - S) in keep_set else None)
                     xs.append(xn)
-                    if keep_set is not None and len(xs) >= 3:
+                    if keep_set is not None and len(xs) >= 3 and chunks is None:     # (with side streams still reading them the tensors stay until the loop's join)
                         xs[-2] = xs[-2] if (len(xs) - 2 - (S + 1)) in keep_set else None
                     xt = xn
             finally:
@@ -282,13 +337,20 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                     _lib.set_concurrent_streams(1)
                     for (_, _, sc) in chunks:
                         torch.cuda.current_stream().wait_stream(sc)        # the caller's stream sees every chunk's results
+                    if keep_set is not None:                               # ... and only now lets go of what nobody asked for
+                        for q in range(1, len(xs) - 1):
+                            if (q - (S + 1)) not in keep_set:
+                                xs[q] = None
             return xs, x0_preds
 
-        graphed = (os.environ.get("WAVEDM_GRAPH", "0") == "1" and not sharded and not multi and n > 0 and not _lib.prof_on() and
+        graphed = (os.environ.get("WAVEDM_GRAPH", "0") == "1" and not sharded and not multi and n > 0 and not _lib.prof_on() and eta == 0.0 and
                    not torch.cuda.is_current_stream_capturing())
         if graphed:
+            # everything the captured launch sequence depends on is in the key: shapes and the model's buffers (in _replay_graph), the timestep
+            # sequence, the patch list, the call size, what is kept, the schedule's bytes (cached per betas tensor: no read-back per call), the temb-table switch
             xs, x0_preds = _replay_graph(unet, run_loop, x, x_cond, x_other, n_run,
-                                         (tuple(seq), None if corners is None else tuple(map(tuple, tri)), p, max_batch, keep_set, n_run, betas.detach().float().cpu().numpy().tobytes()),
+                                         (tuple(seq), None if corners is None else tuple(map(tuple, tri)), p, max_batch, call_b, keep_set, n_run, _betas_entry(betas)[1],
+                                          os.environ.get("WAVEDM_TEMB_TABLE", "1"), str(x_cond.dtype), None if x_other is None else str(x_other.dtype)),
                                          keepalive=(patches, t_dev))
         else:
             xs, x0_preds = run_loop(x, x_cond, x_other, n_run, multi)

@@ -100,13 +100,10 @@ class DiffusionUNet(nn.Module):
         self.out_ch = int(config.model.out_ch)
         self.ch = int(config.model.ch)
         self.temb_ch = self.ch * 4
-        self._dtype_code = resolve_dtype(config, dtype)
-        self._torch_dtype = {_lib.WDM_BF16: torch.bfloat16, _lib.WDM_F16: torch.float16}.get(self._dtype_code, torch.float32)
-        L = _lib.lib()
-        self._cfg = _make_config(config, self._dtype_code)
-        u = C.c_void_p()
-        _lib.check(L.wdm_unet_create(None, C.byref(self._cfg), C.byref(u)))
-        self._u = u
+        self._dtype_fallback = None                          # set by DenoisingDiffusion_Wavelet's automatic f16 choice: the mode to fall back to, loudly
+        self._u = None
+        self._set_dtype(resolve_dtype(config, dtype))
+        L, u = _lib.lib(), self._u
         if self.use_wavelet_in_unet:                         # registered first, like unet.py:204-206 (frozen, state_dict keys only)
             from .wavelet import WaveletTransform
             self.wavelet_dec = WaveletTransform(scale=2, dec=True)
@@ -124,6 +121,26 @@ class DiffusionUNet(nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws, self._ws_need, self._ws_gen = {}, {}, None
+
+    def _set_dtype(self, code):
+        """(Re)create the library object for a compute mode.  The parameter table does not depend on the mode; the packed buffer and the workspaces do."""
+        L = _lib.lib()
+        if getattr(self, "_u", None):
+            L.wdm_unet_destroy(self._u)
+            self._u = None
+        self._dtype_code = code
+        self._torch_dtype = {_lib.WDM_BF16: torch.bfloat16, _lib.WDM_F16: torch.float16}.get(code, torch.float32)
+        self._cfg = _make_config(self.config, code)
+        u = C.c_void_p()
+        _lib.check(L.wdm_unet_create(None, C.byref(self._cfg), C.byref(u)))
+        self._u = u
+        self._packed = None
+        self._packed_sig = None
+        self._ws, self._ws_need, self._ws_gen = {}, {}, None
+
+    @property
+    def dtype_name(self):
+        return {_lib.WDM_F32: "f32", _lib.WDM_BF16: "bf16", _lib.WDM_F32X3: "f32x3", _lib.WDM_F16: "f16"}[self._dtype_code]
 
     @property
     def module(self):
@@ -186,9 +203,21 @@ class DiffusionUNet(nn.Module):
                 self._packed = torch.empty(self.packed_bytes() + 256, dtype=torch.uint8, device=dev)
                 _lib.check(L.wdm_unet_set_packed(self._u, _lib.ptr(self._packed), self._packed.numel()))
             sd = dict(self.named_parameters())
-            for key in self._names:
-                src = sd[key].detach().contiguous()
-                _lib.check(L.wdm_unet_load_param(self._u, key.encode(), _lib.ptr(src), src.numel(), _lib.stream_ptr()))
+            try:
+                for key in self._names:
+                    src = sd[key].detach().contiguous()
+                    _lib.check(L.wdm_unet_load_param(self._u, key.encode(), _lib.ptr(src), src.numel(), _lib.stream_ptr()))
+            except RuntimeError as e:
+                if self._dtype_fallback is None or self._dtype_code != _lib.WDM_F16 or "fp16 range" not in str(e):
+                    raise
+                # the automatic f16 choice met a checkpoint fp16 cannot hold: say so and carry on in the fallback mode (an EXPLICIT dtype='f16' raises instead)
+                import warnings
+                fb, self._dtype_fallback = self._dtype_fallback, None
+                warnings.warn(f"wavedm_amd: THIS CHECKPOINT DOES NOT FIT THE DEFAULT f16 MODE ({e}); falling back to dtype={fb!r} "
+                              f"(16-bit throughput mode, ~3e-3 of the fp32 result instead of <= 1e-3 -- pass dtype='f32x3' for parity at a third of the speed)",
+                              RuntimeWarning, stacklevel=2)
+                self._set_dtype(_lib.DTYPES[fb])
+                return self.pack_weights(force=True)
         self._packed_sig = sig
         return self._packed
 
