@@ -433,7 +433,7 @@ def main():
                 hfrm = d._make_generator("procedural", args.dtype)
                 for S4 in (50, 25):
                     a4 = SimpleNamespace(**vars(a))
-                    a4.sampling_timesteps, a4.images_per_call, a4.max_batch, a4.early_stop, a4.world_size, a4.rank = S4, None, 128, True, 1, 0
+                    a4.sampling_timesteps, a4.images_per_call, a4.max_batch, a4.early_stop, a4.world_size, a4.rank = S4, None, None, True, 1, 0
                     a4.image_folder = os.path.join(root, f"out{S4}")
                     d.args = a4
                     d.generator = ident
@@ -445,7 +445,7 @@ def main():
                             rest4.restore(loader4, validation="raindrop", r=16)
                     t4 = timed(pass_c4)
                     sp4 = spread()
-                    base = {"images": N4, "ddim_steps": S4, "steps_run": S4 - 4, "images_per_sampler_call": per_call, "unet_call_cap": 128, "unit": "img/s", "steps": 3, "warmup": 1}
+                    base = {"images": N4, "ddim_steps": S4, "steps_run": S4 - 4, "images_per_sampler_call": per_call, "unet_call_cap": rest4._max_batch(), "unit": "img/s", "steps": 3, "warmup": 1}
                     extras.append(dict(base, workload=f"BASELINE.json configs[4] per GPU, SAMPLER-ONLY leg of DiffusiveRestoration.restore(): {N4} whole 480x720 images in host memory, 45 "
                                                       f"stitched 64x64 patches each (r = 16), {S4} DDIM steps (early stop at x0_preds[-5]: {S4 - 4} run), identity HFRM stand-in, no PNGs",
                                        value=round(N4 / t4, 3), ms_per_step=round(t4 * 1e3, 1), spread=sp4))

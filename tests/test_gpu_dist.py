@@ -147,9 +147,10 @@ def test_patch_sharded_restore_on_eight_ranks_matches_one_process(tmp_path):
 
 
 def patch8_setup(dev):
-    """One 480x720 image and a 64-resolution UNet of reduced width (ch 32, levels (1, 2), attention at 32) -- shared by the eight ranks and the single process."""
+    """One 480x720 image and the raindrop_wavelet UNet at a quarter of its width (ch 32: 9.8 M parameters, same levels, attention at 16 x 16 and in the middle block)
+    -- shared by the eight ranks and the single process."""
     import wavedm_amd
-    cfg = P.raindrop_wavelet_config(image_size=64, ch=32, ch_mult=(1, 2), attn_resolutions=(32,))
+    cfg = P.raindrop_wavelet_config(image_size=64, ch=32)
     cfg.device = dev
     args = SimpleNamespace(resume="", sampling_timesteps=6, local_rank=dev.index, image_folder="/tmp/wdm_img", test_set="raindrop", grid_r=16, images_per_call=1)
     d = wavedm_amd.DenoisingDiffusion_Wavelet(args, cfg, generator=lambda x: x, dtype="f32")

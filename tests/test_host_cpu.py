@@ -175,6 +175,30 @@ def test_raindrop_dataset_matches_reference_golden(golden, tmp_path):
     assert tuple(x.shape) == (4, 6, 64, 64) and tuple(total.shape) == (4, 3, 480, 720)
 
 
+def test_raindrop_loaders_use_a_fork_server_and_keep_their_workers(tmp_path):
+    """RainDrop.get_loaders with num_workers > 0: worker processes from a fork server (forked children of a process with a HIP context slow its launches tenfold,
+    datasets.worker_kwargs), alive across passes; the items are the ones the in-process loader gives, pass after pass."""
+    import random
+    from types import SimpleNamespace
+    from wavedm_amd.datasets import RainDrop, worker_kwargs
+    O.synthetic_raindrop_dir(str(tmp_path), seed=303)
+    for leaf in ("input", "gt"):
+        os.makedirs(tmp_path / "raindrop" / "train" / leaf)
+    got = {}
+    for nw in (0, 2):
+        cfg = P.reduced_config()
+        cfg.data.data_dir, cfg.data.num_workers = str(tmp_path), nw
+        cfg.training = SimpleNamespace(patch_n=2, batch_size=1)
+        random.seed(3)
+        _, val = RainDrop(SimpleNamespace(world_size=1, rank=0), cfg).get_loaders(parse_patches=False, validation="raindrop")
+        if nw:
+            assert val.multiprocessing_context.get_start_method() == "forkserver" and val.persistent_workers
+        got[nw] = [[(y[0], float(x.double().sum()), tuple(x.shape)) for x, y, t in val] for _ in range(2)]
+    assert got[0][0] == got[2][0] == got[2][1] and len(got[0][0]) == 3
+    cfg.data.worker_context = "fork"
+    assert worker_kwargs(cfg, 2) == {} and worker_kwargs(P.reduced_config(), 0) == {}
+
+
 def test_trainer_param_table_on_host():
     """wdm_trainer_param_info needs no GPU: every state_dict entry of the reference once, offsets tile the flat buffer exactly."""
     from wavedm_amd.unet import _make_config

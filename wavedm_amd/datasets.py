@@ -36,6 +36,24 @@ def eval_size(w: int, h: int):
     return int(16 * np.ceil(w / 16.0)), int(16 * np.ceil(h / 16.0))
 
 
+def worker_kwargs(config, num_workers):
+    """DataLoader keywords for the worker processes.  NOT the reference's default (`fork`): while fork()ed children of a process that holds a HIP context are
+    alive, every kernel launch and allocation of the parent is an order of magnitude slower on this stack (measured, round 6: one group of restore() queued in 1.7 s
+    with eight forked loader workers alive, 0.09 s without, 0.03-0.12 s with `forkserver` / `spawn` workers alive: profiles/r06_restore_fork_interference.log) --
+    the GPU starves for as long as the loader has not been read to its end.  So the workers come from a fork server (a clean process that never touched the GPU; torch
+    pre-imported there once) and stay alive between epochs / passes, which also takes their start-up (~1 s) out of every pass but the first.
+    `config.data.worker_context: fork` restores the reference's behaviour (restore() then reads a short validation set to its end before it launches much)."""
+    ctx = getattr(getattr(config, "data", None), "worker_context", "forkserver")
+    if num_workers <= 0 or ctx in (None, "", "fork"):
+        return {}
+    import multiprocessing as mp
+    try:
+        mp.get_context(ctx).set_forkserver_preload(["torch", "numpy", "PIL.Image", "wavedm_amd.datasets"]) if ctx == "forkserver" else None
+    except Exception:                                   # (a server that is already running keeps its preload list)
+        pass
+    return dict(multiprocessing_context=ctx, persistent_workers=True)
+
+
 class RainDropDataset(torch.utils.data.Dataset):
     def __init__(self, dir, patch_size, n, transforms=None, filelist=None, parse_patches=True):
         super().__init__()
@@ -121,10 +139,11 @@ class RainDrop:
         if not parse_patches:
             cfg.sampling.batch_size = 1
         ws, rank = getattr(self.args, "world_size", 1), getattr(self.args, "rank", 0)
+        wk = worker_kwargs(cfg, cfg.data.num_workers)
         train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=cfg.training.batch_size,
                                                    sampler=DistributedSampler(train_dataset, num_replicas=ws, rank=rank),
-                                                   num_workers=cfg.data.num_workers, pin_memory=True)
+                                                   num_workers=cfg.data.num_workers, pin_memory=True, **wk)
         val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=cfg.sampling.batch_size, shuffle=False,
                                                  sampler=DistributedSampler(val_dataset, num_replicas=ws, rank=rank),
-                                                 num_workers=cfg.data.num_workers, pin_memory=True)
+                                                 num_workers=cfg.data.num_workers, pin_memory=True, **wk)
         return train_loader, val_loader

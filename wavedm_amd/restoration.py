@@ -53,8 +53,39 @@ def save_image(img, path):
     Image.fromarray(a).save(path)
 
 
+class _StageBudget:
+    """Bytes of staged input (pinned host + device copies) the feeder may hold ahead of the sampler."""
+
+    def __init__(self, limit, stop):
+        import threading
+        self.limit, self.used, self.stop, self.cv = max(1, limit), 0, stop, threading.Condition()
+
+    def acquire(self, n):
+        with self.cv:
+            while self.used > 0 and self.used + n > self.limit and not self.stop.is_set():      # (one group always fits)
+                self.cv.wait(0.25)
+            self.used += n
+
+    def release(self, n):
+        with self.cv:
+            self.used -= n
+            self.cv.notify_all()
+
+    def wake(self):
+        with self.cv:
+            self.cv.notify_all()
+
+
 class DiffusiveRestoration:
+    def _mark(self, what):
+        """WAVEDM_RESTORE_TRACE=1: host-side timeline of restore() in self.trace [(seconds since the call, thread, label)] (scripts/restore_trace.py)."""
+        if self.trace is not None:
+            import threading
+            import time
+            self.trace.append((time.perf_counter() - self._t0, threading.current_thread().name, what))
+
     def __init__(self, diffusion, args, config, save_images=True):
+        self.trace = None
         self.args = args
         self.config = config
         self.diffusion = diffusion
@@ -92,16 +123,20 @@ class DiffusiveRestoration:
         cap = max(16, mb // max(P, 1))
         return max(range(1, cap + 1), key=lambda n: (min(fill(n), 0.97), -n))        # the smallest count that reaches 97 %, else the best fill (then the smallest)
 
-    def _feed(self, val_loader, r, q, stop):
+    def _feed(self, val_loader, r, q, stop, budget, hungry):
         """Feeder thread: loader items -> groups of same-sized images -> pinned -> device (copy stream).  Puts (x_dev, names, copy_done_event, pinned) on q,
         an exception if one happened, then None."""
         dev = self.diffusion.device
         try:
             torch.cuda.set_device(dev)
             copy_stream = torch.cuda.Stream(device=dev)
-            group, limit = [], 1
+            group, limit, n_emitted = [], 1, 0
+            auto = getattr(self.args, "images_per_call", None) in (None, 0, "auto", "Auto", "AUTO")
 
             def emit(group):
+                nonlocal n_emitted
+                n_emitted += 1
+                self._mark(f"feeder: group of {len(group)} read")
                 names = [it[1] for it in group]
                 if group[0][0].is_cuda:
                     x = torch.cat([it[0] for it in group], dim=0).float().contiguous()
@@ -117,6 +152,8 @@ class DiffusiveRestoration:
                     xd = xp.to(dev, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
+                self._mark("feeder: group pinned, copy queued")
+                budget.acquire(xp.numel() * 4)
                 q.put((xd, names, ev, xp))
 
             for i, (x, y, total) in enumerate(val_loader):
@@ -126,12 +163,17 @@ class DiffusiveRestoration:
                 for k in range(x.shape[0]):                                    # loader batches are split into images
                     name = y[k] if isinstance(y, (list, tuple)) and len(y) == x.shape[0] else y
                     item = (x[k:k + 1], name)
-                    if group and (len(group) >= limit or group[0][0].shape != item[0].shape):
+                    if group and group[0][0].shape != item[0].shape:           # a different size closes the group
                         emit(group)
                         group = []
                     if not group:
                         limit = self.images_per_call_for(item[0].shape[-2] // 4, item[0].shape[-1] // 4, r)
                     group.append(item)
+                    # full -- or, with automatic grouping, the sampler is WAITING for input (the start of a run, a loader slower than the GPU): what is there goes
+                    # at once, the GPU starts on image 1 while the loader still decodes image 2 (per-image results do not depend on the grouping)
+                    if len(group) >= limit or (auto and hungry.is_set()):
+                        emit(group)
+                        group = []
             if group:
                 emit(group)
         except BaseException as e:                                             # surfaced by restore()
@@ -163,6 +205,7 @@ class DiffusiveRestoration:
         x_output = rec(pred, hf_wav)                                           # :114-115, :124, :134
         H, W = x_output.shape[-2:]
         # the three pairs the reference prints: output, "cond" (IDWT(DWT(x)) == x: the input), HFRM image (restoration.py:146 clamps x_output_wdnet first)
+        self._mark("main: sampler queued")
         sums = torch.stack([imageio.sqdiff(gt, x_output), imageio.sqdiff(gt, inp), imageio.sqdiff(gt, hf.clamp(0.0, 1.0))])
         sums_host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
         sums_host.copy_(sums, non_blocking=True)
@@ -200,37 +243,51 @@ class DiffusiveRestoration:
         if not (cfg.data.wavelet and not cfg.data.wavelet_in_unet and cfg.model.use_other_channels):
             raise NotImplementedError("DiffusiveRestoration.restore: only the raindrop_wavelet.yml branch is accelerated")
         image_folder = os.path.join(self.args.image_folder, cfg.data.dataset, validation)
+        if os.environ.get("WAVEDM_RESTORE_TRACE", "0") == "1":
+            import time
+            self.trace, self._t0 = [], time.perf_counter()
         if self.save_images and self.writer is None:
             self.writer = imageio.AsyncImageWriter()
         acc = {"torch": [], "y": [], "wdnet": []}
         outputs, pending = [], None
-        q, stop = queue.Queue(maxsize=2), threading.Event()
-        feeder = threading.Thread(target=self._feed, args=(val_loader, r, q, stop), name="wavedm-restore-feeder", daemon=True)
+        # groups staged ahead of the sampler: bounded by BYTES (args.prefetch_bytes, default 2 GB of device + pinned memory each), not by count -- a short
+        # validation set is read to its end at once, which also lets a fork-based DataLoader's worker processes exit early (see _StageBudget)
+        q, stop = queue.Queue(), threading.Event()
+        budget = _StageBudget(int(getattr(self.args, "prefetch_bytes", 2 << 30)), stop)
+        hungry = threading.Event()                                              # set while the main thread waits for a group
+        feeder = threading.Thread(target=self._feed, args=(val_loader, r, q, stop, budget, hungry), name="wavedm-restore-feeder", daemon=True)
         feeder.start()
         try:
             with torch.no_grad(), torch.cuda.device(d.device):
                 while True:
-                    staged = q.get()
+                    try:
+                        staged = q.get_nowait()
+                    except queue.Empty:
+                        hungry.set()
+                        staged = q.get()
+                        hungry.clear()
                     if staged is None:
                         break
                     if isinstance(staged, BaseException):
                         raise staged
+                    self._mark("main: group taken")
+                    budget.release(staged[0].numel() * 4 if staged[3] is not None else 0)
                     cur = self._launch_group(staged, r, image_folder)          # group k queued behind group k - 1 ...
+                    self._mark("main: group queued")
                     if pending is not None:
                         outputs += self._finish_group(pending, acc)            # ... before the host waits for k - 1's numbers
+                        self._mark("main: previous group's numbers in")
                     pending = cur
                 if pending is not None:
                     outputs += self._finish_group(pending, acc)
         finally:
             stop.set()
-            while feeder.is_alive():                                           # (an error above: let the feeder run into its stop flag, never block on a full queue)
-                try:
-                    q.get(timeout=0.05)
-                except queue.Empty:
-                    pass
+            budget.wake()                                                      # (an error above: the feeder runs into its stop flag instead of waiting for room)
             feeder.join()
+        self._mark("main: last group done")
         if self.writer is not None:
             self.writer.flush()
+        self._mark("main: PNGs flushed")
         if acc["torch"]:
             print("psnr all torch", float(np.mean(acc["torch"])))
             print("psnr all np", float(np.mean(acc["y"])))
