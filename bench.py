@@ -275,7 +275,7 @@ def main():
         # HBM traffic per launch of that kernel: PMC counters need their own rocprofv3 passes (never combined with the timed
         # run), so the committed summary of scripts/prof_r01.sh is quoted here when it covers the same kernel
         traffic, traffic_src = None, None
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", f"{tag}_traffic.json")))
                 traffic = round(tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"])
@@ -547,7 +547,7 @@ def main():
                                  "achieved": round(d3["flops"] / d3["ms"] / 1e9, 2), "peak": pk3,
                                  "unit": "TFLOP/s (fp32-equivalent: 2 M N K per product)" if name == "f32x3" else "TFLOP/s",
                                  "frac": round(d3["flops"] / d3["ms"] / 1e9 / pk3, 4), "all_conv_tflops": round(sum(e["flops"] for e in rep3) / tot3 / 1e9, 2),
-                                 "conv_ms_per_pass": round(tot3, 2), "profile": f"profiles/r05_kernel_stats_{name}.md"}
+                                 "conv_ms_per_pass": round(tot3, 2), "profile": f"profiles/r06_kernel_stats_{name}.md"}
                 a.sampling_timesteps = 10
             else:
                 rp, xp = P.synthetic_batch(B, patch_px=256, seed=63)

@@ -105,12 +105,23 @@ def stats(d, out):
     for f in find(d, "*kernel_trace.csv"):
         rows.append(pd.read_csv(f))
     df = pd.concat(rows)
+    df = df[df["Kernel_Name"] != "Kernel_Name"].copy()          # (several per-process files concatenated into one: their header lines)
+    for c in ("End_Timestamp", "Start_Timestamp"):
+        df[c] = pd.to_numeric(df[c])
+    # bench.py's board-roof calibration (tools/mfma_power_ubench.hip: k<...> / kl<...>, a CHILD process behind the timed passes; rocprofv3 follows it since ROCm 7.2)
+    # is not part of the measured path: listed on its own line, kept out of the table and of the percentages
+    cal = df["Kernel_Name"].str.match(r"^_Z\d+kl?I")
+    cal_ms, cal_n = float(((df.loc[cal, "End_Timestamp"] - df.loc[cal, "Start_Timestamp"]) / 1e6).sum()), int(cal.sum())
+    df = df[~cal].copy()
     df["k"] = df["Kernel_Name"].map(short)
     df["dur_us"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
     g = df.groupby("k")["dur_us"].agg(["count", "sum", "mean", "min", "max"]).sort_values("sum", ascending=False)
     tot = g["sum"].sum()
     with open(out, "w") as fh:
-        fh.write(f"rocprofv3 --kernel-trace --stats summary ({len(df)} dispatches, {tot / 1e6:.3f} s of kernel time)\n\n")
+        fh.write(f"rocprofv3 --kernel-trace --stats summary ({len(df)} dispatches, {tot / 1e6:.3f} s of kernel time)\n")
+        if cal_n:
+            fh.write(f"(not in the table: {cal_n} dispatches, {cal_ms:.0f} ms of tools/mfma_power_ubench.hip -- bench.py's board-roof calibration, a child process behind the timed passes)\n")
+        fh.write("\n")
         fh.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
         for k, r in g.iterrows():
             fh.write(f"| {k} | {int(r['count'])} | {r['sum'] / 1e3:.2f} | {r['mean']:.2f} | {r['min']:.2f} | {r['max']:.2f} | {100 * r['sum'] / tot:.2f} |\n")

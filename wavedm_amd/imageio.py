@@ -78,9 +78,11 @@ class AsyncImageWriter:
     Several threads take the FIFO order away, so saves to the SAME path are ordered explicitly: every save gets a per-path sequence number, a worker holds the path's
     lock while it writes and skips its item when a later save to that path has been queued -- the last save wins, as with one thread."""
 
-    def __init__(self, max_pending: int = 64, workers: int = 0):
+    def __init__(self, max_pending: int = 512, workers: int = 0):
+        # max_pending: restore() hands over a whole group's files (7 per image) without waiting; workers: one round of encoding for the ~50 files a group of seven
+        # 480x720 images leaves at its end (a 480x720 PNG of incompressible data takes PIL ~55 ms)
         self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
-        n = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 4))
+        n = workers if workers > 0 else max(1, min(64, (os.cpu_count() or 2) // 4))
         self._threads = [threading.Thread(target=self._run, name=f"wavedm-png-writer-{k}", daemon=True) for k in range(n)]
         self._stream = None
         self._errors = []

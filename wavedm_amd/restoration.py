@@ -198,10 +198,22 @@ class DiffusiveRestoration:
         early = bool(getattr(self.args, "early_stop", True))
         if int(self.diffusion.args.sampling_timesteps) < 5:
             raise IndexError("x0_preds[-5] needs at least 5 sampling steps (restoration.py:108)")
+        rec = lambda lo, hi: d.wavelet_rec.compose(lo, hi, pc)                    # IDWT(cat([lo[:, :pc], hi[:, pc:]])) -> clamp((x + 1) / 2), one kernel
+        names = [n[0] if isinstance(n, (list, tuple)) else n for n in names]
+        w = self.writer if self.save_images else None
+        if w is not None:
+            # five of the reference's seven PNGs per image do not depend on the sampler: converted and handed to the writer BEFORE the sampler is queued, so that
+            # they are encoded while it runs and only two per image are left for the end of the group (the order of the files on disk is nobody's contract)
+            for k, name in enumerate(names):
+                sl = slice(k, k + 1)
+                w.save(rec(x_gt[sl], hf_wav[sl]), os.path.join(image_folder, f"{name}_lrgt_hrwdnet.png"))      # :118-120, :158
+                w.save(hf[sl], os.path.join(image_folder, f"{name}_all_wdnet.png"))
+                w.save(rec(x_gt[sl], x_cond[sl]), os.path.join(image_folder, f"{name}_lrgt_hrcond.png"))       # :121-123
+                w.save(inp[sl], os.path.join(image_folder, f"{name}_cond.png"))
+                w.save(gt[sl], os.path.join(image_folder, f"{name}_gt.png"))
         xs, x0_preds = self.diffusive_restoration(x_cond, x_other=x_other, r=r, last=False, total=None,
                                                   use_global=False, use_other=True, stop_at=-5 if early else None)
         pred = x0_preds[-5]                                                    # :108
-        rec = lambda lo, hi: d.wavelet_rec.compose(lo, hi, pc)                    # IDWT(cat([lo[:, :pc], hi[:, pc:]])) -> clamp((x + 1) / 2), one kernel
         x_output = rec(pred, hf_wav)                                           # :114-115, :124, :134
         H, W = x_output.shape[-2:]
         # the three pairs the reference prints: output, "cond" (IDWT(DWT(x)) == x: the input), HFRM image (restoration.py:146 clamps x_output_wdnet first)
@@ -211,18 +223,11 @@ class DiffusiveRestoration:
         sums_host.copy_(sums, non_blocking=True)
         done = torch.cuda.Event()
         done.record(cur)
-        names = [n[0] if isinstance(n, (list, tuple)) else n for n in names]
-        if self.save_images:
-            w = self.writer
+        if w is not None:
             for k, name in enumerate(names):
                 sl = slice(k, k + 1)
-                w.save(rec(x_gt[sl], hf_wav[sl]), os.path.join(image_folder, f"{name}_lrgt_hrwdnet.png"))      # :118-120, :158
-                w.save(hf[sl], os.path.join(image_folder, f"{name}_all_wdnet.png"))
-                w.save(rec(x_gt[sl], x_cond[sl]), os.path.join(image_folder, f"{name}_lrgt_hrcond.png"))       # :121-123
-                w.save(rec(pred[sl], x_gt[sl]), os.path.join(image_folder, f"{name}_lrdiff_hrgt.png"))         # :112-113
                 w.save(x_output[sl], os.path.join(image_folder, f"{name}_output.png"))
-                w.save(inp[sl], os.path.join(image_folder, f"{name}_cond.png"))
-                w.save(gt[sl], os.path.join(image_folder, f"{name}_gt.png"))
+                w.save(rec(pred[sl], x_gt[sl]), os.path.join(image_folder, f"{name}_lrdiff_hrgt.png"))         # :112-113
         return dict(names=names, out=x_output, sums=sums_host, done=done, HW=(H, W), keep=(pinned, sums))
 
     def _finish_group(self, g, acc):
