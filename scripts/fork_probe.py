@@ -40,7 +40,25 @@ def loops(tag):
     for h in host:
         h[0] = 1; h[4096] = 1
     t6 = time.perf_counter()
-    print(f"{tag:<34s} torch add_ {1e3 * (t1 - t0) / 2:7.1f} us/launch   wdm_dwt_fwd {1e3 * (t3 - t2) / 2:7.1f} us/call   torch.empty {1e3 * (t5 - t4) / 2:7.1f} us   heap touch {1e3 * (t6 - t5):7.2f} ms", flush=True)
+    extra = ""
+    if pin is not None:                                      # write the pinned buffer (allocated BEFORE the fork) on the host, then DMA it to the device
+        dst = torch.empty(pin.numel(), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        pin.fill_(3)
+        t8 = time.perf_counter()
+        dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t9 = time.perf_counter()
+        fresh = torch.empty(pin.numel(), dtype=torch.uint8, pin_memory=True)       # ... and the same with a pinned buffer allocated NOW
+        fresh.fill_(3)
+        t10 = time.perf_counter()
+        dst.copy_(fresh, non_blocking=True)
+        torch.cuda.synchronize()
+        t11 = time.perf_counter()
+        del fresh
+        extra = f"   pinned {pin.numel() >> 20} MB: host write {1e3 * (t8 - t7):7.1f} ms, H2D {1e3 * (t9 - t8):7.1f} ms | fresh block: alloc + write {1e3 * (t10 - t9):7.1f} ms, H2D {1e3 * (t11 - t10):7.1f} ms"
+    print(f"{tag:<34s} torch add_ {1e3 * (t1 - t0) / 2:7.1f} us/launch   wdm_dwt_fwd {1e3 * (t3 - t2) / 2:7.1f} us/call   torch.empty {1e3 * (t5 - t4) / 2:7.1f} us   heap touch {1e3 * (t6 - t5):7.2f} ms{extra}", flush=True)
 
 
 loops("before any fork")

@@ -55,18 +55,37 @@ def main():
     if os.environ.get("PIN", "1") == "0" or os.environ.get("MPCTX"):
         val_loader = torch.utils.data.DataLoader(val_loader.dataset, batch_size=1, shuffle=False, num_workers=W, pin_memory=os.environ.get("PIN", "1") == "1",
                                                  multiprocessing_context=os.environ.get("MPCTX") or None)
+    if os.environ.get("SYNTH") == "1":                      # no PIL, no files: items made by torch.rand in the workers
+        class Synth(torch.utils.data.Dataset):
+            def __len__(self):
+                return N
+
+            def __getitem__(self, i):
+                x = torch.rand(6, 480, 720, generator=torch.Generator().manual_seed(i))
+                return x, str(i), x[:3]
+        val_loader = torch.utils.data.DataLoader(Synth(), batch_size=1, shuffle=False, num_workers=W, pin_memory=os.environ.get("PIN", "1") == "1",
+                                                 multiprocessing_context=os.environ.get("MPCTX") or None)
     t_iter = time.perf_counter()
     n = sum(1 for _ in val_loader)
     print(f"loader alone: {n} items in {time.perf_counter() - t_iter:.3f} s ({W} workers)")
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        src = iter(val_loader) if os.environ.get("ITER_MAIN") == "1" else val_loader        # ITER_MAIN=1: the workers are fork()ed from the MAIN thread, not from restore()'s feeder thread
         with contextlib.redirect_stdout(io.StringIO()):
-            rest.restore(val_loader, validation="raindrop", r=16)
+            rest.restore(src, validation="raindrop", r=16)
         torch.cuda.synchronize()
         print(f"pass {rep}: {time.perf_counter() - t0:.3f} s = {N / (time.perf_counter() - t0):.2f} img/s")
-    for t, th, what in rest.trace:
-        print(f"  {t * 1e3:9.1f} ms  {th:<24s} {what}")
+    if os.environ.get("STEPS") == "1":
+        from wavedm_amd import sampling
+        sampling._TRACE = rest._mark
+        with contextlib.redirect_stdout(io.StringIO()):
+            rest.restore(iter(val_loader) if os.environ.get("ITER_MAIN") == "1" else val_loader, validation="raindrop", r=16)
+    torch.cuda.synchronize()
+    ev0 = next((e[3] for e in rest.trace if e[3] is not None), None)
+    for t, th, what, ev in rest.trace:
+        gpu = f"   GPU reaches it {ev0.elapsed_time(ev):9.1f} ms after the first mark" if ev is not None else ""
+        print(f"  {t * 1e3:9.1f} ms  {th:<24s} {what}{gpu}")
     shutil.rmtree(root, ignore_errors=True)
 
 

@@ -37,11 +37,11 @@ def eval_size(w: int, h: int):
 
 
 def worker_kwargs(config, num_workers):
-    """DataLoader keywords for the worker processes.  NOT the reference's default (`fork`): while fork-started DataLoader workers of a process that holds a HIP context
-    are alive, queueing GPU work from that process is an order of magnitude slower on this stack (measured, round 6: one group of restore() queued in 1.7-2.4 s with eight
-    forked loader workers alive, 0.09 s without, 0.03-0.12 s with `forkserver` / `spawn` workers alive: profiles/r06_restore_fork_interference.log; children that merely
-    sleep after os.fork() do not have the effect, profiles/r06_fork_probe.log -- it takes workers that keep running torch code on the inherited address space) --
-    the GPU starves for as long as the loader has not been read to its end.  So the workers come from a fork server (a clean process that never touched the GPU; torch
+    """DataLoader keywords for the worker processes.  NOT the reference's default (`fork`): after a process that holds a HIP context has fork()ed its DataLoader workers,
+    its GPU queue does not start executing newly queued work for ~2 s on this stack (measured, round 6, GPU-side event timestamps: the stream's first event completes 1.9 s
+    after it was queued, then everything runs at full speed; the host meanwhile sits in a launch call with the queue full -- profiles/r06_restore_fork_interference.log,
+    section E; it ends early when the children exit; `forkserver` / `spawn` workers cause nothing, nor do children that merely sleep after os.fork() in a small process,
+    profiles/r06_fork_probe.log).  Two seconds per iter(loader): a quarter of a 58-image evaluation, every pass of a benchmark.  So the workers come from a fork server (a clean process that never touched the GPU; torch
     pre-imported there once) and stay alive between epochs / passes, which also takes their start-up (~1 s) out of every pass but the first.
     `config.data.worker_context: fork` restores the reference's behaviour (restore() then reads a short validation set to its end before it launches much)."""
     ctx = getattr(getattr(config, "data", None), "worker_context", "forkserver")

@@ -82,7 +82,11 @@ class DiffusiveRestoration:
         if self.trace is not None:
             import threading
             import time
-            self.trace.append((time.perf_counter() - self._t0, threading.current_thread().name, what))
+            ev = None
+            if threading.current_thread() is threading.main_thread() and os.environ.get("WAVEDM_RESTORE_TRACE_GPU", "0") == "1":
+                ev = torch.cuda.Event(enable_timing=True)                       # when the GPU gets to this point of the main stream
+                ev.record(torch.cuda.current_stream(self.diffusion.device))
+            self.trace.append((time.perf_counter() - self._t0, threading.current_thread().name, what, ev))
 
     def __init__(self, diffusion, args, config, save_images=True):
         self.trace = None
@@ -192,7 +196,9 @@ class DiffusiveRestoration:
         inp, gt = x[:, :3].contiguous(), x[:, 3:].contiguous()
         x_cond = d.wavelet_dec.forward_affine(inp)                             # restoration.py:79, :88: DWT(2x - 1) in one kernel
         x_gt = d.wavelet_dec.forward_affine(gt)                                # :89
+        self._mark("main: DWTs queued")
         hf = d.generator(inp)                                                  # :94 (HFRM)
+        self._mark("main: HFRM queued")
         hf_wav = d.wavelet_dec.forward_affine(hf.contiguous())                 # :95-96
         x_other = hf_wav[:, ob:].contiguous()                                  # :102
         early = bool(getattr(self.args, "early_stop", True))

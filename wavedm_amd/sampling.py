@@ -37,6 +37,8 @@ def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_time
 
 DEFAULT_MAX_BATCH = 384      # patches per UNet call of the stitched sampler when args.max_batch is not set (workspace ~ 40 MB per patch: 15 GB of the 288)
 
+_TRACE = None       # scripts/restore_trace.py: a callable(label) for host-side timeline marks inside the loop
+
 _ABAR = {}          # id(betas tensor) -> (weak reference to it, its version counter, (abar table on the host, the betas' bytes))
 _DEVCONST = {}      # small read-only device tensors the launches read through raw pointers (patch lists, timestep rows)
 
@@ -284,6 +286,8 @@ def ddim_sample(unet, x, x_cond, x_other, seq, betas, corners=None, p_size=None,
                 _lib.set_concurrent_streams(len(chunks))                  # tile rules that count one launch's workgroups count the chunks' together (whole loop)
             try:
                 for k, (i_t, j_t) in enumerate(zip(reversed(seq), reversed(seq_next))):
+                    if _TRACE is not None:
+                        _TRACE(f"sampler: step {k}")
                     if k >= n_steps:
                         x0_preds.append(None)
                         xs.append(None)
