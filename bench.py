@@ -161,17 +161,17 @@ def main():
         args.batch = 256 if args.batch == 64 else args.batch
     if args.workload == "c4":
         args.ddim_steps = 50 if args.ddim_steps == 100 else args.ddim_steps
-        # per GPU: one image per sampler call at N = 1 (the reference's loop shape); with N > 1 the throughput form of §8f-2 --
-        # 8 images per GPU in ONE stitched sampler call, UNet batches of 128 (5.2 vs 3.8 img/s per GPU)
+        # per GPU: DiffusiveRestoration.restore() with its own defaults -- early stop at x0_preds[-5], 7 images per stitched sampler call (315 patches = one UNet
+        # call under the cap of 384), groups pipelined -- over 14 images per pass
         multi = args.gpus > 1
         if args.patch_sharded:
             if not multi:
                 fail("--patch-sharded needs --gpus > 1", args.gpus, rank)
             args.batch, args.images_per_call = (1 if args.batch == 64 else args.batch), 1
         elif args.batch == 64:
-            args.batch = 8
+            args.batch = 14                                       # two sampler calls of seven images (restore()'s automatic grouping: 7 x 45 patches fill a UNet call)
         if not args.max_batch:
-            args.max_batch = 128
+            args.max_batch = 384
     cfg = P.raindrop_wavelet_config(image_size=128 if args.workload == "c2" else 64)
     cfg.device = dev
     a = SimpleNamespace(resume="", sampling_timesteps=args.ddim_steps, local_rank=local_dev, image_folder="/tmp/wdm",

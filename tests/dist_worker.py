@@ -34,9 +34,14 @@ def main(out_path):
         rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
         torch.manual_seed(77 + 1000 * rank)                         # ranks draw DIFFERENT start noise: the sampler must spread rank 0's
         outs, psnr = rest.restore([(img, ("one",), torch.zeros(1))], validation="raindrop", r=16)
+        # ... and two images with the AUTOMATIC grouping (args.images_per_call unset): every rank must form the same groups whatever its loader's timing
+        args2 = SimpleNamespace(**{k: v for k, v in vars(args).items() if k != "images_per_call"})
+        rest2 = wavedm_amd.DiffusiveRestoration(d, args2, d.config, save_images=False)
+        torch.manual_seed(78 + 1000 * rank)
+        outs2, _ = rest2.restore([(img, ("a",), torch.zeros(1)), (img.flip(-1), ("b",), torch.zeros(1))], validation="raindrop", r=16)
         shards = [parallel.shard_range(45, r_, world)[1] - parallel.shard_range(45, r_, world)[0] for r_ in range(world)]
         if rank == 0:
-            torch.save({"out": outs[0].cpu(), "psnr": psnr[0], "world": world, "shards": shards}, out_path)
+            torch.save({"out": outs[0].cpu(), "psnr": psnr[0], "world": world, "shards": shards, "out2": [o.cpu() for o in outs2]}, out_path)
         dist.barrier()
         dist.destroy_process_group()
         return

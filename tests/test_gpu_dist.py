@@ -144,6 +144,12 @@ def test_patch_sharded_restore_on_eight_ranks_matches_one_process(tmp_path):
     outs, psnr = rest.restore([(img, ("one",), torch.zeros(1))], validation="raindrop", r=16)
     assert rel_linf(got["out"], outs[0].cpu()) <= 1e-5
     assert abs(got["psnr"] - psnr[0]) <= 1e-3
+    # two images, automatic grouping on every rank (one group of two: the patch-sharded mode forms no timing-dependent partial groups)
+    args2 = SimpleNamespace(**{k: v for k, v in vars(args).items() if k != "images_per_call"})
+    rest2 = wavedm_amd.DiffusiveRestoration(d, args2, d.config, save_images=False)
+    torch.manual_seed(78)
+    outs2, _ = rest2.restore([(img, ("a",), torch.zeros(1)), (img.flip(-1), ("b",), torch.zeros(1))], validation="raindrop", r=16)
+    assert len(got["out2"]) == 2 and all(rel_linf(got["out2"][k], outs2[k].cpu()) <= 1e-5 for k in range(2))
 
 
 def patch8_setup(dev):

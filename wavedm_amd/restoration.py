@@ -135,7 +135,8 @@ class DiffusiveRestoration:
             torch.cuda.set_device(dev)
             copy_stream = torch.cuda.Stream(device=dev)
             group, limit, n_emitted = [], 1, 0
-            auto = getattr(self.args, "images_per_call", None) in (None, 0, "auto", "Auto", "AUTO")
+            # partial groups are a timing decision of THIS process: never in the patch-sharded mode, where every rank must form the same groups (one all-reduce per step)
+            auto = (getattr(self.args, "images_per_call", None) in (None, 0, "auto", "Auto", "AUTO")) and getattr(self.diffusion, "patch_group", None) is None
 
             def emit(group):
                 nonlocal n_emitted
