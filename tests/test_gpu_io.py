@@ -128,6 +128,15 @@ def test_restore_surfaces_loader_errors_and_short_schedules(tmp_path):
     rest = wavedm_amd.DiffusiveRestoration(d, args, d.config, save_images=False)
     with pytest.raises(OSError, match="truncated PNG"):
         rest.restore(bad_loader(), validation="raindrop", r=4)
+    assert rest.restore([], validation="raindrop", r=4) == ([], [])                      # an empty loader: nothing queued, nothing printed
+    # a loader batch of several images, 5-D as a parse_patches loader yields them (restoration.py:72 flattens): split into images, the items keep their order
+    g = torch.Generator().manual_seed(8)
+    xb = torch.rand(1, 3, 6, 64, 80, generator=g)
+    torch.manual_seed(3)
+    o5, _ = rest.restore([(xb, ("p",), torch.zeros(1))], validation="raindrop", r=4)
+    torch.manual_seed(3)
+    o1, _ = rest.restore([(xb[0, k:k + 1], (f"p{k}",), torch.zeros(1)) for k in range(3)], validation="raindrop", r=4)
+    assert len(o5) == 3 and all(torch.equal(a, b) for a, b in zip(o5, o1))
     d4, a4 = _diffusion(4)                                      # x0_preds[-5] of a 4-step run: the reference's IndexError (restoration.py:108)
     a4.image_folder = str(tmp_path)
     with pytest.raises(IndexError):
