@@ -8,7 +8,7 @@
 `eval` = eval_diffusion.py (DiffusiveRestoration.restore over the validation loader), `train` = train_diffusion.py (diffusion.train).
 --config is a file name under ./configs or a path.  Under torchrun every rank restores its share of the validation images (the
 loaders use a DistributedSampler) and rank 0 prints the PSNR over all of them; training all-reduces gradients over RCCL.
-Extras: --dtype {f16,bf16,f32x3,f32} (default: f16 when the checkpoint fits fp16, else bf16 with a warning), --images_per_call N (eval: images per sampler call), --hfrm_ckpt PATH, --max_steps N (train)."""
+Extras: --dtype {f16,bf16,f32x3,f32} (default: f16 when the checkpoint fits fp16, else bf16 with a warning), --images_per_call N (eval: images per sampler call, default automatic), --full_length (eval: no early stop), --hfrm_ckpt PATH, --max_steps N (train)."""
 import argparse
 import os
 import random
@@ -36,11 +36,14 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=61)
     ap.add_argument("--ema", action="store_true", help="eval: load the EMA weights of the checkpoint")
     ap.add_argument("--dtype", default=None, choices=["f16", "bf16", "f32x3", "f32"])
-    ap.add_argument("--images_per_call", type=int, default=1)
+    ap.add_argument("--images_per_call", type=int, default=0, help="eval: images per sampler call; 0 = automatic (as many same-sized images as fill the UNet calls), 1 = the reference's loop")
+    ap.add_argument("--full_length", action="store_true", help="eval: also run the four DDIM steps behind x0_preds[-5], which restore() never reads (the reference's step count)")
     ap.add_argument("--hfrm_ckpt", default=None)
     ap.add_argument("--max_steps", type=int, default=None)
     ap.add_argument("--no_save", action="store_true", help="eval: metrics only, no PNGs")
     a = ap.parse_args(argv)
+    a.early_stop = not a.full_length
+    a.images_per_call = a.images_per_call or None          # None: DiffusiveRestoration's automatic grouping
     a.rank = int(os.environ.get("RANK", 0))
     a.world_size = int(os.environ.get("WORLD_SIZE", 1))
     a.local_rank = int(os.environ.get("LOCAL_RANK", 0))
