@@ -242,7 +242,11 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         rank_elapsed = [float(tmin.item()), float(tmax.item())]
         elapsed = rank_elapsed[1]                                        # the job is as slow as its slowest rank
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         gathered = parallel.all_gather_shards(out, B * world)          # outside the timed region
+        torch.cuda.synchronize()
+        gather_s, gather_bytes = time.perf_counter() - tg, gathered.numel() * gathered.element_size()
         assert gathered.shape[0] == B * world
     finite = bool(torch.isfinite(out).all())
 
@@ -628,6 +632,7 @@ def main():
             if sharded_one:
                 res["scaling"] = "strong"                                            # the same image(s) whatever N is
             res["rccl"] = {"rccl_ranks": world, "backend": backend, "weight_broadcast_s": round(bcast_s, 4) if bcast_s is not None else None,
+                           "weight_broadcast_bytes": int(d.model.packed_bytes()), "output_all_gather_s": round(gather_s, 4), "output_all_gather_bytes": int(gather_bytes),
                            **({"patch_shards": [parallel.shard_range(45 * B, r_, world)[1] - parallel.shard_range(45 * B, r_, world)[0] for r_ in range(world)],
                                "allreduce_bytes_per_step": 2 * B * 3 * 120 * 180 * 4} if sharded_one else {}),
                            "rank_elapsed_s_min": round(min(rank_elapsed), 4), "rank_elapsed_s_max": round(max(rank_elapsed), 4)}
