@@ -19,10 +19,22 @@ dwt = WaveletTransform(scale=2, dec=True)
 pin = torch.empty(int(os.environ.get("PIN_MB", "0")) << 20, dtype=torch.uint8, pin_memory=True) if os.environ.get("PIN_MB") else None
 ws = torch.empty(int(os.environ.get("WS_GB", "0")) << 30, dtype=torch.uint8, device=dev) if os.environ.get("WS_GB") else None
 host = [bytearray(1 << 20) for _ in range(int(os.environ.get("HEAP_MB", "0")))]      # private, written heap pages of the parent
+if pin is not None and os.environ.get("DONTFORK") == "1":                              # keep the pinned pages out of the children: no copy-on-write on them at fork()
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6", use_errno=True)
+    a0 = pin.data_ptr() & ~4095
+    n = ((pin.data_ptr() + pin.numel() + 4095) & ~4095) - a0
+    rc = libc.madvise(ctypes.c_void_p(a0), ctypes.c_size_t(n), 10)                    # MADV_DONTFORK
+    print("madvise(MADV_DONTFORK) on the pinned buffer:", rc, ctypes.get_errno(), flush=True)
 
 
 def loops(tag):
+    # completion latency first: one tiny kernel, queued and waited for (a stalled GPU queue shows here, not in the host-side enqueue times below)
+    c0 = time.perf_counter()
+    x.add_(1.0)
     torch.cuda.synchronize()
+    lat = time.perf_counter() - c0
+    print(f"{tag:<34s} first kernel queued -> complete: {1e3 * lat:9.2f} ms", flush=True)
     t0 = time.perf_counter()
     for _ in range(2000):
         x.add_(1.0)

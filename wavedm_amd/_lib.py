@@ -216,3 +216,28 @@ def require_cuda_f32(t, name):
         raise TypeError(f"{name}: expected a float32 tensor on the GPU (got {getattr(t, 'dtype', type(t))} on "
                         f"{getattr(t, 'device', '?')}); wavedm_amd has no CPU path")
     return t.contiguous()
+
+
+_LIBC = None
+
+
+def pinned_dontfork(t):
+    """madvise(MADV_DONTFORK) on a pinned host tensor's bytes; returns t.  Why (round 6, scripts/fork_probe.py, profiles/r06_fork_probe.log): when a process that holds a HIP
+    context fork()s -- a DataLoader starting its workers -- its GPU queue does not run new work until the driver has sorted out every page of PINNED host memory the fork
+    made copy-on-write: ~21 ms per MB (0.2 s for a bare process, 5.7 s with 512 MB pinned, on an MI355X box).  Pinned staging buffers are of no use to a child; kept out of
+    fork() they cost nothing.  Page-granular and idempotent; a failure (non-Linux libc, odd mapping) is ignored -- it only costs the stall back."""
+    global _LIBC
+    try:
+        if t is None or not t.is_pinned():
+            return t
+        if _LIBC is None:
+            _LIBC = C.CDLL("libc.so.6", use_errno=True)
+            _LIBC.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+            _LIBC.madvise.restype = C.c_int
+        a0 = t.data_ptr() & ~4095
+        n = ((t.data_ptr() + t.numel() * t.element_size() + 4095) & ~4095) - a0
+        if n > 0:
+            _LIBC.madvise(a0, n, 10)                    # MADV_DONTFORK
+    except Exception:                                   # noqa: BLE001
+        pass
+    return t

@@ -37,11 +37,12 @@ def eval_size(w: int, h: int):
 
 
 def worker_kwargs(config, num_workers):
-    """DataLoader keywords for the worker processes.  NOT the reference's default (`fork`): after a process that holds a HIP context has fork()ed its DataLoader workers,
-    its GPU queue does not start executing newly queued work for ~2 s on this stack (measured, round 6, GPU-side event timestamps: the stream's first event completes 1.9 s
-    after it was queued, then everything runs at full speed; the host meanwhile sits in a launch call with the queue full -- profiles/r06_restore_fork_interference.log,
-    section E; it ends early when the children exit; `forkserver` / `spawn` workers cause nothing, nor do children that merely sleep after os.fork() in a small process,
-    profiles/r06_fork_probe.log).  Two seconds per iter(loader): a quarter of a 58-image evaluation, every pass of a benchmark.  So the workers come from a fork server (a clean process that never touched the GPU; torch
+    """DataLoader keywords for the worker processes.  NOT the reference's default (`fork`): every fork() of a process that holds a HIP context stalls its GPU queue once,
+    for ~0.2 s + ~21 ms per MB of PINNED host memory the process holds (scripts/fork_probe.py, profiles/r06_fork_probe.log: 1.8 s with 64 MB pinned, 10.9 s with 512 MB; device
+    memory and ordinary heap do not count) -- hipHostMalloc pages go copy-on-write at fork and the queue waits until the driver has them back.  restore() holds staging
+    buffers, PNG buffers and the loader's pinned batches: ~2 s per iter(loader) (profiles/r06_restore_fork_interference.log, section E: GPU-side timestamps), a quarter of a
+    58-image evaluation, every pass of a benchmark.  Workers from a fork server never fork the GPU process.  (The pinned buffers this package allocates are also kept out of
+    fork() -- _lib.pinned_dontfork -- which removes their share of the stall for loaders that do fork.)  So the workers come from a fork server (a clean process that never touched the GPU; torch
     pre-imported there once) and stay alive between epochs / passes, which also takes their start-up (~1 s) out of every pass but the first.
     `config.data.worker_context: fork` restores the reference's behaviour (restore() then reads a short validation set to its end before it launches much)."""
     ctx = getattr(getattr(config, "data", None), "worker_context", "forkserver")

@@ -123,7 +123,7 @@ class AsyncImageWriter:
         if self._stream is None or self._stream.device != dev:
             self._stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
-        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        host = _lib.pinned_dontfork(torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True))      # (pinned pages a later fork() need not make copy-on-write: _lib.pinned_dontfork)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             host.copy_(u8, non_blocking=True)

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from .ddm_wavelet import data_transform, inverse_data_transform
-from . import imageio, sampling
+from . import _lib, imageio, sampling
 
 
 def torchPSNR(tar_img, prd_img):
@@ -150,9 +150,9 @@ class DiffusiveRestoration:
                     q.put((x, names, ev, None))
                     return
                 # gathered straight into pinned memory (the host allocator recycles these blocks once their copies are done)
-                xp = torch.empty((len(group),) + tuple(group[0][0].shape[1:]), dtype=torch.float32, pin_memory=True)
+                xp = _lib.pinned_dontfork(torch.empty((len(group),) + tuple(group[0][0].shape[1:]), dtype=torch.float32, pin_memory=True))
                 for k, it in enumerate(group):
-                    xp[k].copy_(it[0][0])
+                    xp[k].copy_(_lib.pinned_dontfork(it[0])[0])                # (a pin_memory=True loader's own pinned batch: kept out of the NEXT fork as well)
                 with torch.cuda.stream(copy_stream):
                     xd = xp.to(dev, non_blocking=True)
                     ev = torch.cuda.Event()
@@ -226,7 +226,7 @@ class DiffusiveRestoration:
         # the three pairs the reference prints: output, "cond" (IDWT(DWT(x)) == x: the input), HFRM image (restoration.py:146 clamps x_output_wdnet first)
         self._mark("main: sampler queued")
         sums = torch.stack([imageio.sqdiff(gt, x_output), imageio.sqdiff(gt, inp), imageio.sqdiff(gt, hf.clamp(0.0, 1.0))])
-        sums_host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
+        sums_host = _lib.pinned_dontfork(torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True))
         sums_host.copy_(sums, non_blocking=True)
         done = torch.cuda.Event()
         done.record(cur)
