@@ -165,6 +165,7 @@ class DenoisingDiffusion_Wavelet(object):
         """One iteration of the reference's loop body (:208-272) on a batch of crops x (n, 6, p, p): DWT, q-sample with antithetic
         timesteps, loss, backward, gradient all-reduce, Adam, EMA.  Returns the loss as a device tensor."""
         tr = getattr(self, "trainer", None) or self.make_trainer()
+        _lib.pinned_dontfork(x)                          # (a pin_memory=True loader's batch: not copy-on-write at the loader's next fork -- _lib.pinned_dontfork)
         x = x.flatten(start_dim=0, end_dim=1) if x.ndim == 5 else x
         loss = tr.train_step(self.assemble_training_sample(x), group=group)
         self.step = tr.step
