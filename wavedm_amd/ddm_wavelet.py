@@ -316,14 +316,14 @@ class DenoisingDiffusion_Wavelet(object):
         _, c, h, w = x_cond.shape
         return sampling.overlapping_grid_indices(h, w, output_size, r)
 
-    def diffusive_restoration(self, x_cond, x_other=None, r=None, last=True, total=None, use_global=False, use_other=False):
-        """ddm_wavelet.py:413-424."""
+    def diffusive_restoration(self, x_cond, x_other=None, r=None, last=True, total=None, use_global=False, use_other=False, stop_at=None):
+        """ddm_wavelet.py:413-424.  `stop_at`: see sample_image."""
         p_size = self.config.data.patch_size if self.config.data.wavelet_in_unet else self.config.data.image_size
         h_list, w_list = self.overlapping_grid_indices(x_cond, output_size=p_size, r=r)
         corners = [(i, j) for i in h_list for j in w_list]
         x = torch.randn((x_cond.shape[0], self.config.model.pred_channels, x_cond.shape[2], x_cond.shape[3]), device=self.device)
         return self.sample_image(x_cond, x, x_other=x_other, patch_locs=corners, last=last, patch_size=p_size,
-                                 total=total, use_global=use_global, use_other=use_other)
+                                 total=total, use_global=use_global, use_other=use_other, stop_at=stop_at)
 
     def restore(self, val_loader, validation="snow", r=None, epoch=0):
         """ddm_wavelet.py:340-411, the training loop's validation sheet: the first two items of `val_loader` are restored and
@@ -347,7 +347,8 @@ class DenoisingDiffusion_Wavelet(object):
                 x_gt = self.wavelet_dec(x_all[:, 3:].contiguous())
                 hf_wav = self.wavelet_dec(data_transform(self.generator(inp)).contiguous())
                 _, x0_preds = self.diffusive_restoration(x_cond, x_other=hf_wav[:, ob:].contiguous(), r=r, last=False,
-                                                         use_global=False, use_other=True)
+                                                         use_global=False, use_other=True,
+                                                         stop_at=-5 if getattr(self.args, "early_stop", True) else None)      # only x_output_list[1][-5] is read (ddm_wavelet.py:378)
                 pred = x0_preds[-5]
                 rec = lambda lo, hi: inverse_data_transform(self.wavelet_rec(torch.cat([lo[:, :pc], hi[:, pc:]], dim=1).contiguous()))
                 x_output, hrgt = rec(pred, hf_wav), rec(pred, x_gt)
